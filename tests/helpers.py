@@ -1,0 +1,21 @@
+"""Shared test helpers: golden-case loading and bit-pattern comparison."""
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+CASES = ["monkey_mesh_128", "monkey_mesh_160x90", "monkey_mesh_1080p_crop", "world_128", "world_1280x720_crop",
+         "cornell_geo_128", "cornell_geo_1080p_crop", "suzanne_geo_96"]
+
+
+def load_case(name):
+    return dict(np.load(os.path.join(GOLDEN, f"case_{name}.npz")))
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def n_bit_mismatch(a, b):
+    return int((bits(a) != bits(b)).sum())
