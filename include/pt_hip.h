@@ -1,0 +1,174 @@
+/*
+ * pt_hip.h -- C ABI of the MI355X (gfx950) path-tracing core.
+ *
+ * This library stands where the reference host dispatches its GLSL program: everything the fragment shader
+ * data/shaders/pathtracing.fs computed per pixel (camera ray, closest hit over 10 spheres or the triangle mesh,
+ * modified-Phong bounce with the shader's interleaved-gradient-noise RNG, sky, running-mean accumulation) is
+ * done by hand-written HIP kernels behind these entry points. Plain C types only; no exceptions, no aborts:
+ * every call returns a PtStatus and pt_last_error() holds the message of the calling thread's last failure.
+ *
+ * Ownership: the library owns all device memory it allocates. Host pointers passed in are read (or written)
+ * during the call only -- uploads copy synchronously, like glTexImage2D, so the caller may free its arrays
+ * right after the call returns. A context is bound to one HIP device and one stream and must be driven by one
+ * host thread at a time. Multi-GPU: one context per device.
+ *
+ * Numerics contract: fp32, no fused multiply-add except where the reference's software GL evaluates one, IEEE
+ * division and square root, denormals flushed to zero, and the GLSL built-ins sin/cos/exp2/pow evaluated with
+ * the same polynomial forms as Mesa llvmpipe. With it, images are bit-identical to the reference shader run
+ * on llvmpipe.
+ *
+ * Each entry point cites the reference interface (file:line under the reference checkout) that it replaces.
+ */
+#ifndef PT_HIP_H
+#define PT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_ABI_VERSION 1
+
+typedef enum PtStatus {
+    PT_OK = 0,
+    PT_ERR_INVALID_ARGUMENT = 1, /* null pointer, negative size, index out of range, ... */
+    PT_ERR_HIP = 2,              /* a HIP runtime call failed; pt_last_error() carries hipGetErrorString */
+    PT_ERR_STATE = 3,            /* call sequence error: no target, no program in use, no mesh uploaded, ... */
+    PT_ERR_NO_DEVICE = 4,        /* no usable gfx950 device / device index out of range */
+    PT_ERR_UNSUPPORTED = 5
+} PtStatus;
+
+/* Which closest-hit call the program makes. The reference keeps both calls in its shader and comments one out
+ * (pathtracing.fs:395-396): as committed it traces the 10 spheres ("world"); "mesh" is the other line. */
+typedef enum PtProgramKind {
+    PT_PROGRAM_WORLD = 0, /* IntersectWorld, pathtracing.fs:83-121, call at :395 */
+    PT_PROGRAM_MESH = 1   /* IntersectMesh,  pathtracing.fs:125-174, call at :396 */
+} PtProgramKind;
+
+/* Shading normal of a mesh hit. */
+typedef enum PtNormalMode {
+    PT_NORMALS_VERTEX = 0,   /* barycentric blend of the three vertex normals, pathtracing.fs:164-165 */
+    PT_NORMALS_GEOMETRIC = 1 /* normalize(cross(e1,e2)), the alternative the shader carries at pathtracing.fs:166;
+                                for OBJ files without per-vertex normals (the reference host reads those out of
+                                bounds, PathTracer.cpp:1191-1193) */
+} PtNormalMode;
+
+/* How a dispatch folds a sample into the target. */
+typedef enum PtAccumMode {
+    PT_ACCUM_MEAN = 0, /* out = prev + (1/u_Samples)*(sample - prev): the shader's mix(), pathtracing.fs:414 */
+    PT_ACCUM_SUM = 1   /* out = prev + sample: running sum, like Framebuffer.h:46,51-52; what sample-split ranks
+                          produce before their sums are merged and divided by the sample count */
+} PtAccumMode;
+
+/* The program's uniforms (pathtracing.fs:6-9,17-18), set per frame at PathTracer.cpp:1372-1382.
+ * u_Samples (pathtracing.fs:19) is not here: it is the sample index that pt_dispatch() is given. */
+typedef struct PtUniforms {
+    float camera_position[3];          /* u_CameraPosition */
+    float camera_lower_left_corner[3]; /* u_CameraLowerLeftCorner */
+    float camera_horizontal[3];        /* u_CameraHorizontal */
+    float camera_vertical[3];          /* u_CameraVertical */
+    int32_t num_triangles;             /* u_NumTriangles: how many of the uploaded triangles are traced */
+    int32_t depth;                     /* u_Depth: bounce limit, 10 in the reference */
+} PtUniforms;
+
+/* Filled by pt_get_stats(). Times are HIP-event times on the context's stream. */
+typedef struct PtStats {
+    uint64_t rays;             /* closest-hit queries since the last pt_reset_stats(): one per bounce-loop iteration
+                                  (the reference's definition, PathTracer.cpp:947; its GLSL mode never counts, :1315) */
+    uint64_t samples;          /* pixel-samples (shader invocations) */
+    uint32_t dispatches;       /* render-kernel launches */
+    float last_dispatch_ms;    /* duration of the most recent render kernel; 0 unless timing is enabled */
+    double total_dispatch_ms;  /* sum over dispatches since the last reset; 0 unless timing is enabled */
+} PtStats;
+
+typedef struct PtContext PtContext; /* opaque */
+
+/* ---- library / context ------------------------------------------------------------------------------- */
+
+int32_t pt_abi_version(void);
+/* Message of the calling thread's most recent failing call ("" if none). Never NULL. */
+const char* pt_last_error(void);
+/* Number of HIP devices visible to the process. */
+PtStatus pt_device_count(int32_t* count);
+/* Replaces window + GL context creation (PathTracer.cpp:1072-1112): binds device `device`, creates a stream. */
+PtStatus pt_create(int32_t device, PtContext** out_ctx);
+/* Replaces the teardown at PathTracer.cpp:1502-1517. Frees every device allocation of the context. */
+PtStatus pt_destroy(PtContext* ctx);
+/* Use an existing HIP stream (hipStream_t passed as void*; NULL = back to the context's own stream). The caller
+ * keeps ownership of the stream. For hosts that already order their own work on a stream (e.g. torch). */
+PtStatus pt_set_stream(PtContext* ctx, void* hip_stream);
+
+/* ---- program object: stands in for Shader (Shader.h:18-27) ---------------------------------------------- */
+
+/* Replaces Shader::loadFragmentShader + createProgram (Shader.cpp:361-373, 86-107; called at
+ * PathTracer.cpp:1248-1251): selects the kernel family. *out_program is a non-zero handle. */
+PtStatus pt_program_create(PtContext* ctx, PtProgramKind kind, uint32_t* out_program);
+/* Replaces Shader::destroyProgram (Shader.cpp:59-66). */
+PtStatus pt_program_destroy(PtContext* ctx, uint32_t program);
+/* Replaces glUseProgram(program) (PathTracer.cpp:1371). */
+PtStatus pt_use_program(PtContext* ctx, uint32_t program);
+
+/* ---- scene upload: replaces the four glTexImage2D uploads (PathTracer.cpp:1253-1288) -------------------- */
+
+/* count spheres as (cx,cy,cz,r); the shader always loops over 10 (pathtracing.fs:87), so count must be 10.
+ * Replaces the spheres texture, PathTracer.cpp:1253-1258. */
+PtStatus pt_upload_spheres(PtContext* ctx, const float* xyzr, int32_t count);
+/* count materials as (r,g,b,type). Kept resident for interface parity: the shader fetches the material and then
+ * overwrites it with vec4(0.5) (pathtracing.fs:228-229). Replaces PathTracer.cpp:1260-1265. */
+PtStatus pt_upload_materials(PtContext* ctx, const float* rgbt, int32_t count);
+/* Mesh in the reference's layouts: `vertices` = num_vertices x {position xyz, normal xyz} (struct Vertex,
+ * PathTracer.cpp:71-75), `indices` = num_triangles x 3 vertex indices. Replaces the index and vertex textures
+ * (PathTracer.cpp:1267-1288) without their 1024-texel limit. On the device the mesh becomes per-triangle
+ * structure-of-arrays records (edges, normals) in HBM; triangle id = position in `indices`. */
+PtStatus pt_upload_mesh(PtContext* ctx, const float* vertices, int32_t num_vertices, const uint32_t* indices,
+                        int32_t num_triangles);
+PtStatus pt_set_normal_mode(PtContext* ctx, PtNormalMode mode);
+
+/* ---- accumulation target: replaces the two RGBA32F textures + FBOs (PathTracer.cpp:1136-1152) ------------ */
+
+/* Two width x height RGBA32F images (row 0 = bottom row, like GL), cleared to (0,0,0,1). Each pass reads one and
+ * writes the other, then they swap (PathTracer.cpp:1306,1384,1398,1493). */
+PtStatus pt_target_create(PtContext* ctx, int32_t width, int32_t height);
+/* Same, but in caller-owned device memory (two buffers of width*height*4 floats, 16-byte aligned): lets a host
+ * that manages device memory itself (torch tensors, RCCL buffers) merge results without a copy. The buffers are
+ * NOT cleared. `rgba_b` may equal `rgba_a` for in-place accumulation. */
+PtStatus pt_target_bind_external(PtContext* ctx, void* rgba_a, void* rgba_b, int32_t width, int32_t height);
+/* glClear with the reference's clear colour (0,0,0,1) on both images (PathTracer.cpp:1108,1151); with
+ * PT_ACCUM_SUM in effect the clear colour is (0,0,0,0). */
+PtStatus pt_target_clear(PtContext* ctx);
+/* Restricts rendering to the pixel window [x0,x0+w) x [y0,y0+h) (glScissor semantics); pixels outside keep their
+ * value. Used for the image-tile partition across GPUs. w = h = 0 restores the full frame. */
+PtStatus pt_set_window(PtContext* ctx, int32_t x0, int32_t y0, int32_t w, int32_t h);
+PtStatus pt_set_accum_mode(PtContext* ctx, PtAccumMode mode);
+
+/* ---- per-frame: replaces PathTracer.cpp:1370-1403 ------------------------------------------------------ */
+
+/* Replaces the glUniform* block, PathTracer.cpp:1372-1382. */
+PtStatus pt_set_uniforms(PtContext* ctx, const PtUniforms* uniforms);
+/* Replaces bind + glDrawArrays (PathTracer.cpp:1384-1402), asynchronously on the context's stream.
+ * Renders `num_samples` consecutive passes u_Samples = first_sample, first_sample + stride, ... for every pixel of
+ * the window and leaves the result in the current image, exactly as that many reference frames would (the
+ * running mean is carried in registers between passes instead of through memory). num_samples = 1, stride = 1
+ * is one reference frame. first_sample is 1-based (PathTracer.cpp:1305,1378). */
+PtStatus pt_dispatch(PtContext* ctx, int32_t first_sample, int32_t num_samples, int32_t stride);
+/* Replaces glFinish (PathTracer.cpp:1403): waits for the stream and reports any kernel fault. */
+PtStatus pt_finish(PtContext* ctx);
+
+/* ---- results (new: the reference never reads back, it only presents) ------------------------------------ */
+
+/* Copies the current image (the one the last pass wrote) to host: width*height*4 floats, row 0 = bottom. */
+PtStatus pt_readback_rgba32f(PtContext* ctx, float* dst);
+/* Device address of the current image (for hosts that consume it on the device). */
+PtStatus pt_current_image(PtContext* ctx, void** out_device_ptr);
+/* Traces primary rays only and copies per-pixel closest-hit ids (int32; -1 = miss; sphere id for
+ * PT_PROGRAM_WORLD, triangle id for PT_PROGRAM_MESH) and hit distances (1e38 on a miss). Either may be NULL. */
+PtStatus pt_readback_primary(PtContext* ctx, int32_t* ids, float* t);
+PtStatus pt_enable_timing(PtContext* ctx, int32_t enabled);
+PtStatus pt_get_stats(PtContext* ctx, PtStats* out);
+PtStatus pt_reset_stats(PtContext* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PT_HIP_H */

@@ -1,0 +1,219 @@
+"""ctypes binding of the C ABI declared in include/pt_hip.h (library: pathtracer_amd/lib/libpt_hip.so).
+
+There is no fallback: if the library is missing, or a call fails, an exception is raised. The library is built
+in-tree by pathtracer_amd/build.py (hipcc, gfx950).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpt_hip.so")
+
+PT_OK = 0
+PT_ERR_INVALID_ARGUMENT, PT_ERR_HIP, PT_ERR_STATE, PT_ERR_NO_DEVICE, PT_ERR_UNSUPPORTED = 1, 2, 3, 4, 5
+PROGRAM_WORLD, PROGRAM_MESH = 0, 1
+NORMALS_VERTEX, NORMALS_GEOMETRIC = 0, 1
+ACCUM_MEAN, ACCUM_SUM = 0, 1
+
+
+class PtUniforms(C.Structure):
+    _fields_ = [("camera_position", C.c_float * 3), ("camera_lower_left_corner", C.c_float * 3),
+                ("camera_horizontal", C.c_float * 3), ("camera_vertical", C.c_float * 3),
+                ("num_triangles", C.c_int32), ("depth", C.c_int32)]
+
+
+class PtStats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("samples", C.c_uint64), ("dispatches", C.c_uint32),
+                ("last_dispatch_ms", C.c_float), ("total_dispatch_ms", C.c_double)]
+
+
+class PtError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"pt_hip status {status}: {message}")
+        self.status = status
+
+
+# name -> (restype, argtypes); every symbol include/pt_hip.h declares
+SIGNATURES = {
+    "pt_abi_version": (C.c_int32, []),
+    "pt_last_error": (C.c_char_p, []),
+    "pt_device_count": (C.c_int, [C.POINTER(C.c_int32)]),
+    "pt_create": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p)]),
+    "pt_destroy": (C.c_int, [C.c_void_p]),
+    "pt_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pt_program_create": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint32)]),
+    "pt_program_destroy": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "pt_use_program": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "pt_upload_spheres": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "pt_upload_materials": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "pt_upload_mesh": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),
+    "pt_set_normal_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "pt_target_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "pt_target_bind_external": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+    "pt_target_clear": (C.c_int, [C.c_void_p]),
+    "pt_set_window": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "pt_set_accum_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "pt_set_uniforms": (C.c_int, [C.c_void_p, C.POINTER(PtUniforms)]),
+    "pt_dispatch": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "pt_finish": (C.c_int, [C.c_void_p]),
+    "pt_readback_rgba32f": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pt_current_image": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "pt_readback_primary": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pt_enable_timing": (C.c_int, [C.c_void_p, C.c_int32]),
+    "pt_get_stats": (C.c_int, [C.c_void_p, C.POINTER(PtStats)]),
+    "pt_reset_stats": (C.c_int, [C.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads libpt_hip.so and binds every entry point. Raises if the library has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python -m pathtracer_amd.build` (needs hipcc). "
+                               "There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(status):
+    if status != PT_OK:
+        raise PtError(status, load().pt_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    n = C.c_int32(0)
+    check(load().pt_device_count(C.byref(n)))
+    return n.value
+
+
+class Tracer:
+    """One context (device + stream) with the calls of include/pt_hip.h as methods. Thin: argument packing only."""
+
+    def __init__(self, device=0):
+        self._lib = load()
+        self._ctx = C.c_void_p()
+        check(self._lib.pt_create(device, C.byref(self._ctx)))
+        self.width = self.height = 0
+
+    def close(self):
+        if self._ctx:
+            self._lib.pt_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- program
+    def program_create(self, kind):
+        h = C.c_uint32(0)
+        check(self._lib.pt_program_create(self._ctx, kind, C.byref(h)))
+        return h.value
+
+    def program_destroy(self, program):
+        check(self._lib.pt_program_destroy(self._ctx, program))
+
+    def use_program(self, program):
+        check(self._lib.pt_use_program(self._ctx, program))
+
+    def set_stream(self, hip_stream):
+        check(self._lib.pt_set_stream(self._ctx, C.c_void_p(hip_stream)))
+
+    # -- scene
+    def upload_spheres(self, xyzr):
+        a = np.ascontiguousarray(xyzr, np.float32).reshape(-1, 4)
+        check(self._lib.pt_upload_spheres(self._ctx, a.ctypes.data, len(a)))
+
+    def upload_materials(self, rgbt):
+        a = np.ascontiguousarray(rgbt, np.float32).reshape(-1, 4)
+        check(self._lib.pt_upload_materials(self._ctx, a.ctypes.data, len(a)))
+
+    def upload_mesh(self, vertices, indices):
+        v = np.ascontiguousarray(vertices, np.float32).reshape(-1, 6)
+        i = np.ascontiguousarray(indices, np.uint32).reshape(-1, 3)
+        check(self._lib.pt_upload_mesh(self._ctx, v.ctypes.data, len(v), i.ctypes.data, len(i)))
+
+    def set_normal_mode(self, mode):
+        check(self._lib.pt_set_normal_mode(self._ctx, mode))
+
+    # -- target
+    def target_create(self, width, height):
+        check(self._lib.pt_target_create(self._ctx, width, height))
+        self.width, self.height = width, height
+
+    def target_bind_external(self, ptr_a, ptr_b, width, height):
+        check(self._lib.pt_target_bind_external(self._ctx, C.c_void_p(ptr_a), C.c_void_p(ptr_b), width, height))
+        self.width, self.height = width, height
+
+    def target_clear(self):
+        check(self._lib.pt_target_clear(self._ctx))
+
+    def set_window(self, x0=0, y0=0, w=0, h=0):
+        check(self._lib.pt_set_window(self._ctx, x0, y0, w, h))
+
+    def set_accum_mode(self, mode):
+        check(self._lib.pt_set_accum_mode(self._ctx, mode))
+
+    # -- per frame
+    def set_uniforms(self, camera12, num_triangles, depth=10):
+        cam = np.asarray(camera12, np.float32).reshape(12)
+        u = PtUniforms()
+        for k in range(3):
+            u.camera_position[k] = cam[k]
+            u.camera_lower_left_corner[k] = cam[3 + k]
+            u.camera_horizontal[k] = cam[6 + k]
+            u.camera_vertical[k] = cam[9 + k]
+        u.num_triangles, u.depth = int(num_triangles), int(depth)
+        check(self._lib.pt_set_uniforms(self._ctx, C.byref(u)))
+
+    def dispatch(self, first_sample, num_samples=1, stride=1):
+        check(self._lib.pt_dispatch(self._ctx, first_sample, num_samples, stride))
+
+    def finish(self):
+        check(self._lib.pt_finish(self._ctx))
+
+    # -- results
+    def readback(self):
+        out = np.empty((self.height, self.width, 4), np.float32)
+        check(self._lib.pt_readback_rgba32f(self._ctx, out.ctypes.data))
+        return out
+
+    def current_image_ptr(self):
+        p = C.c_void_p()
+        check(self._lib.pt_current_image(self._ctx, C.byref(p)))
+        return p.value
+
+    def readback_primary(self):
+        ids = np.empty((self.height, self.width), np.int32)
+        t = np.empty((self.height, self.width), np.float32)
+        check(self._lib.pt_readback_primary(self._ctx, ids.ctypes.data, t.ctypes.data))
+        return ids, t
+
+    def enable_timing(self, on=True):
+        check(self._lib.pt_enable_timing(self._ctx, 1 if on else 0))
+
+    def stats(self):
+        s = PtStats()
+        check(self._lib.pt_get_stats(self._ctx, C.byref(s)))
+        return {"rays": s.rays, "samples": s.samples, "dispatches": s.dispatches,
+                "last_dispatch_ms": s.last_dispatch_ms, "total_dispatch_ms": s.total_dispatch_ms}
+
+    def reset_stats(self):
+        check(self._lib.pt_reset_stats(self._ctx))

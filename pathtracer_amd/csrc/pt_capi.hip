@@ -1,0 +1,569 @@
+// C ABI (include/pt_hip.h) over the HIP runtime. No exceptions leave this file; every failure becomes a
+// PtStatus plus a thread-local message.
+#include "../../include/pt_hip.h"
+#include "pt_internal.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+namespace {
+
+thread_local char g_error[512] = "";
+
+PtStatus fail(PtStatus code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof g_error, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define PT_HIP_TRY(expr)                                                                                     \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess) return fail(PT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));        \
+    } while (0)
+
+#define PT_REQUIRE(cond, code, ...)            \
+    do {                                       \
+        if (!(cond)) return fail(code, __VA_ARGS__); \
+    } while (0)
+
+struct Program {
+    uint32_t handle;
+    PtProgramKind kind;
+};
+
+}  // namespace
+
+struct PtContext {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+
+    std::vector<Program> programs;
+    uint32_t next_program = 1;
+    uint32_t current_program = 0;
+
+    // scene
+    float* d_spheres = nullptr;
+    float* d_materials = nullptr;
+    int32_t num_materials = 0;
+    bool have_spheres = false;
+    float* d_vertices = nullptr;    // raw upload, reference layout (6 floats per vertex)
+    uint32_t* d_indices = nullptr;  // raw upload
+    int32_t num_vertices = 0, num_triangles = 0;
+    float* d_tris = nullptr;        // SoA records, rebuilt when the mesh or the camera position changes
+    float* d_vnormals = nullptr;
+    float* d_gnormals = nullptr;
+    bool records_valid = false;
+    float records_ro[3] = {0, 0, 0};
+
+    // target
+    float* d_image[2] = {nullptr, nullptr};
+    bool image_owned = false;
+    int32_t width = 0, height = 0;
+    int current = 0;  // image the NEXT pass writes is image[current]; the last written is image[current ^ 1]
+    int32_t win[4] = {0, 0, 0, 0};
+    PtAccumMode accum_mode = PT_ACCUM_MEAN;
+    PtNormalMode normal_mode = PT_NORMALS_VERTEX;
+    int32_t* d_ids = nullptr;
+    float* d_t = nullptr;
+
+    // uniforms
+    PtUniforms uniforms{};
+    bool have_uniforms = false;
+
+    // stats
+    unsigned long long* d_counters = nullptr;  // [0] rays
+    uint64_t samples = 0;
+    uint32_t dispatches = 0;
+    bool timing = false;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool ev_pending = false;
+    float last_ms = 0.f;
+    double total_ms = 0.0;
+};
+
+namespace {
+
+PtStatus bind(PtContext* ctx) {
+    PT_REQUIRE(ctx != nullptr, PT_ERR_INVALID_ARGUMENT, "null context");
+    PT_HIP_TRY(hipSetDevice(ctx->device));
+    return PT_OK;
+}
+
+const Program* find_program(const PtContext* ctx, uint32_t handle) {
+    for (const Program& p : ctx->programs)
+        if (p.handle == handle) return &p;
+    return nullptr;
+}
+
+PtStatus collect_timing(PtContext* ctx) {
+    if (ctx->ev_pending) {
+        PT_HIP_TRY(hipEventSynchronize(ctx->ev_stop));
+        float ms = 0.f;
+        PT_HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
+        ctx->last_ms = ms;
+        ctx->total_ms += ms;
+        ctx->ev_pending = false;
+    }
+    return PT_OK;
+}
+
+void free_target(PtContext* ctx) {
+    if (ctx->image_owned) {
+        if (ctx->d_image[0]) (void)hipFree(ctx->d_image[0]);
+        if (ctx->d_image[1] && ctx->d_image[1] != ctx->d_image[0]) (void)hipFree(ctx->d_image[1]);
+    }
+    ctx->d_image[0] = ctx->d_image[1] = nullptr;
+    ctx->image_owned = false;
+    if (ctx->d_ids) (void)hipFree(ctx->d_ids);
+    if (ctx->d_t) (void)hipFree(ctx->d_t);
+    ctx->d_ids = nullptr;
+    ctx->d_t = nullptr;
+    ctx->width = ctx->height = 0;
+}
+
+void free_mesh(PtContext* ctx) {
+    float** f[] = {&ctx->d_vertices, &ctx->d_tris, &ctx->d_vnormals, &ctx->d_gnormals};
+    for (float** q : f) {
+        if (*q) (void)hipFree(*q);
+        *q = nullptr;
+    }
+    if (ctx->d_indices) (void)hipFree(ctx->d_indices);
+    ctx->d_indices = nullptr;
+    ctx->num_vertices = ctx->num_triangles = 0;
+    ctx->records_valid = false;
+}
+
+// Makes sure the per-triangle records match the current mesh and camera position.
+PtStatus ensure_records(PtContext* ctx) {
+    const float* ro = ctx->uniforms.camera_position;
+    if (ctx->records_valid && memcmp(ro, ctx->records_ro, sizeof ctx->records_ro) == 0) return PT_OK;
+    PT_HIP_TRY(pt_launch_prepare_triangles(ctx->d_vertices, ctx->d_indices, ctx->num_triangles, ro, ctx->d_tris,
+                                           ctx->d_vnormals, ctx->d_gnormals, ctx->stream));
+    memcpy(ctx->records_ro, ro, sizeof ctx->records_ro);
+    ctx->records_valid = true;
+    return PT_OK;
+}
+
+PtStatus fill_params(PtContext* ctx, PtKernelParams* p, const Program** prog_out) {
+    PT_REQUIRE(ctx->d_image[0] != nullptr, PT_ERR_STATE, "no accumulation target: call pt_target_create first");
+    PT_REQUIRE(ctx->have_uniforms, PT_ERR_STATE, "uniforms not set: call pt_set_uniforms first");
+    const Program* prog = find_program(ctx, ctx->current_program);
+    PT_REQUIRE(prog != nullptr, PT_ERR_STATE, "no program in use: call pt_use_program first");
+    const PtUniforms& u = ctx->uniforms;
+    memset(p, 0, sizeof *p);
+    memcpy(p->ro, u.camera_position, 12);
+    memcpy(p->llc, u.camera_lower_left_corner, 12);
+    memcpy(p->hor, u.camera_horizontal, 12);
+    memcpy(p->ver, u.camera_vertical, 12);
+    p->width = ctx->width;
+    p->height = ctx->height;
+    p->win_x0 = ctx->win[0]; p->win_y0 = ctx->win[1]; p->win_w = ctx->win[2]; p->win_h = ctx->win[3];
+    p->depth = u.depth;
+    p->accum_mode = (int32_t)ctx->accum_mode;
+    p->normal_mode = (int32_t)ctx->normal_mode;
+    p->counters = ctx->d_counters;
+    if (prog->kind == PT_PROGRAM_MESH) {
+        PT_REQUIRE(u.num_triangles >= 0 && u.num_triangles <= ctx->num_triangles, PT_ERR_INVALID_ARGUMENT,
+                   "u_NumTriangles = %d but %d triangles are uploaded", u.num_triangles, ctx->num_triangles);
+        p->num_triangles = u.num_triangles;
+        if (u.num_triangles > 0) {
+            PtStatus s = ensure_records(ctx);
+            if (s != PT_OK) return s;
+        }
+        p->tris = ctx->d_tris;
+        p->vnormals = ctx->d_vnormals;
+        p->gnormals = ctx->d_gnormals;
+    } else {
+        PT_REQUIRE(ctx->have_spheres, PT_ERR_STATE, "no spheres uploaded: call pt_upload_spheres first");
+        p->spheres = ctx->d_spheres;
+    }
+    *prog_out = prog;
+    return PT_OK;
+}
+
+}  // namespace
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+int32_t pt_abi_version(void) { return PT_ABI_VERSION; }
+
+const char* pt_last_error(void) { return g_error; }
+
+PtStatus pt_device_count(int32_t* count) {
+    PT_REQUIRE(count != nullptr, PT_ERR_INVALID_ARGUMENT, "count is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(PT_ERR_NO_DEVICE, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return PT_OK;
+}
+
+PtStatus pt_create(int32_t device, PtContext** out_ctx) {
+    PT_REQUIRE(out_ctx != nullptr, PT_ERR_INVALID_ARGUMENT, "out_ctx is null");
+    *out_ctx = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(PT_ERR_NO_DEVICE, "no HIP device available (%s)", e == hipSuccess ? "count is 0" : hipGetErrorString(e));
+    PT_REQUIRE(device >= 0 && device < n, PT_ERR_NO_DEVICE, "device %d out of range [0,%d)", device, n);
+    PT_HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    PT_HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(PT_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 code only", device, prop.gcnArchName);
+    PtContext* ctx = new (std::nothrow) PtContext();
+    PT_REQUIRE(ctx != nullptr, PT_ERR_HIP, "out of host memory");
+    ctx->device = device;
+    hipError_t err = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+    if (err == hipSuccess) err = hipMalloc(&ctx->d_counters, 2 * sizeof(unsigned long long));
+    if (err == hipSuccess) err = hipMemsetAsync(ctx->d_counters, 0, 2 * sizeof(unsigned long long), ctx->own_stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(ctx->own_stream);
+    if (err == hipSuccess) err = hipMalloc(&ctx->d_spheres, 40 * sizeof(float));
+    if (err == hipSuccess) err = hipEventCreate(&ctx->ev_start);
+    if (err == hipSuccess) err = hipEventCreate(&ctx->ev_stop);
+    if (err != hipSuccess) {
+        pt_destroy(ctx);
+        return fail(PT_ERR_HIP, "context set-up failed: %s", hipGetErrorString(err));
+    }
+    ctx->stream = ctx->own_stream;
+    *out_ctx = ctx;
+    return PT_OK;
+}
+
+PtStatus pt_destroy(PtContext* ctx) {
+    if (!ctx) return PT_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    free_target(ctx);
+    free_mesh(ctx);
+    if (ctx->d_spheres) (void)hipFree(ctx->d_spheres);
+    if (ctx->d_materials) (void)hipFree(ctx->d_materials);
+    if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+    if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return PT_OK;
+}
+
+PtStatus pt_set_stream(PtContext* ctx, void* hip_stream) {
+    PtStatus s = bind(ctx);
+    if (s != PT_OK) return s;
+    s = collect_timing(ctx);
+    if (s != PT_OK) return s;
+    PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return PT_OK;
+}
+
+PtStatus pt_program_create(PtContext* ctx, PtProgramKind kind, uint32_t* out_program) {
+    PT_REQUIRE(ctx != nullptr && out_program != nullptr, PT_ERR_INVALID_ARGUMENT, "null argument");
+    *out_program = 0;
+    PT_REQUIRE(kind == PT_PROGRAM_WORLD || kind == PT_PROGRAM_MESH, PT_ERR_INVALID_ARGUMENT, "unknown program kind %d", (int)kind);
+    Program p;
+    p.handle = ctx->next_program++;
+    p.kind = kind;
+    ctx->programs.push_back(p);
+    *out_program = p.handle;
+    return PT_OK;
+}
+
+PtStatus pt_program_destroy(PtContext* ctx, uint32_t program) {
+    PT_REQUIRE(ctx != nullptr, PT_ERR_INVALID_ARGUMENT, "null context");
+    for (size_t i = 0; i < ctx->programs.size(); ++i) {
+        if (ctx->programs[i].handle == program) {
+            ctx->programs.erase(ctx->programs.begin() + (long)i);
+            if (ctx->current_program == program) ctx->current_program = 0;
+            return PT_OK;
+        }
+    }
+    return fail(PT_ERR_INVALID_ARGUMENT, "unknown program handle %u", program);
+}
+
+PtStatus pt_use_program(PtContext* ctx, uint32_t program) {
+    PT_REQUIRE(ctx != nullptr, PT_ERR_INVALID_ARGUMENT, "null context");
+    PT_REQUIRE(find_program(ctx, program) != nullptr, PT_ERR_INVALID_ARGUMENT, "unknown program handle %u", program);
+    ctx->current_program = program;
+    return PT_OK;
+}
+
+PtStatus pt_upload_spheres(PtContext* ctx, const float* xyzr, int32_t count) {
+    PtStatus s = bind(ctx);
+    if (s != PT_OK) return s;
+    PT_REQUIRE(xyzr != nullptr, PT_ERR_INVALID_ARGUMENT, "xyzr is null");
+    PT_REQUIRE(count == 10, PT_ERR_INVALID_ARGUMENT, "the program loops over exactly 10 spheres; got %d", count);
+    PT_HIP_TRY(hipMemcpyAsync(ctx->d_spheres, xyzr, 40 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->have_spheres = true;
+    return PT_OK;
+}
+
+PtStatus pt_upload_materials(PtContext* ctx, const float* rgbt, int32_t count) {
+    PtStatus s = bind(ctx);
+    if (s != PT_OK) return s;
+    PT_REQUIRE(rgbt != nullptr && count > 0, PT_ERR_INVALID_ARGUMENT, "rgbt is null or count <= 0");
+    PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->d_materials) (void)hipFree(ctx->d_materials);
+    ctx->d_materials = nullptr;
+    PT_HIP_TRY(hipMalloc(&ctx->d_materials, (size_t)count * 4 * sizeof(float)));
+    PT_HIP_TRY(hipMemcpyAsync(ctx->d_materials, rgbt, (size_t)count * 4 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->num_materials = count;
+    return PT_OK;
+}
+
+PtStatus pt_upload_mesh(PtContext* ctx, const float* vertices, int32_t num_vertices, const uint32_t* indices,
+                        int32_t num_triangles) {
+    PtStatus s = bind(ctx);
+    if (s != PT_OK) return s;
+    PT_REQUIRE(vertices != nullptr && indices != nullptr, PT_ERR_INVALID_ARGUMENT, "null mesh arrays");
+    PT_REQUIRE(num_vertices > 0 && num_triangles > 0, PT_ERR_INVALID_ARGUMENT, "empty mesh (%d vertices, %d triangles)",
+               num_vertices, num_triangles);
+    // A stray index would make the gather kernel read outside the vertex buffer: check on the host first.
+    for (size_t i = 0; i < (size_t)num_triangles * 3; ++i)
+        PT_REQUIRE(indices[i] < (uint32_t)num_vertices, PT_ERR_INVALID_ARGUMENT,
+                   "index %u (corner %zu) out of range for %d vertices", indices[i], i, num_vertices);
+    PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    free_mesh(ctx);
+    const size_t nt = (size_t)num_triangles;
+    PT_HIP_TRY(hipMalloc(&ctx->d_vertices, (size_t)num_vertices * 6 * sizeof(float)));
+    PT_HIP_TRY(hipMalloc(&ctx->d_indices, nt * 3 * sizeof(uint32_t)));
+    PT_HIP_TRY(hipMalloc(&ctx->d_tris, nt * PT_TRI_FLOATS * sizeof(float)));
+    PT_HIP_TRY(hipMalloc(&ctx->d_vnormals, nt * 9 * sizeof(float)));
+    PT_HIP_TRY(hipMalloc(&ctx->d_gnormals, nt * 3 * sizeof(float)));
+    PT_HIP_TRY(hipMemcpyAsync(ctx->d_vertices, vertices, (size_t)num_vertices * 6 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    PT_HIP_TRY(hipMemcpyAsync(ctx->d_indices, indices, nt * 3 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->num_vertices = num_vertices;
+    ctx->num_triangles = num_triangles;
+    ctx->records_valid = false;
+    return PT_OK;
+}
+
+PtStatus pt_set_normal_mode(PtContext* ctx, PtNormalMode mode) {
+    PT_REQUIRE(ctx != nullptr, PT_ERR_INVALID_ARGUMENT, "null context");
+    PT_REQUIRE(mode == PT_NORMALS_VERTEX || mode == PT_NORMALS_GEOMETRIC, PT_ERR_INVALID_ARGUMENT, "unknown normal mode %d", (int)mode);
+    ctx->normal_mode = mode;
+    return PT_OK;
+}
+
+static PtStatus target_common(PtContext* ctx, int32_t width, int32_t height) {
+    ctx->width = width;
+    ctx->height = height;
+    ctx->current = 0;
+    ctx->win[0] = 0; ctx->win[1] = 0; ctx->win[2] = width; ctx->win[3] = height;
+    const size_t n = (size_t)width * height;
+    PT_HIP_TRY(hipMalloc(&ctx->d_ids, n * sizeof(int32_t)));
+    PT_HIP_TRY(hipMalloc(&ctx->d_t, n * sizeof(float)));
+    return PT_OK;
+}
+
+PtStatus pt_target_create(PtContext* ctx, int32_t width, int32_t height) {
+    PtStatus s = bind(ctx);
+    if (s != PT_OK) return s;
+    PT_REQUIRE(width > 0 && height > 0 && width <= 65536 && height <= 65536, PT_ERR_INVALID_ARGUMENT, "bad target size %dx%d", width, height);
+    PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    free_target(ctx);
+    const size_t bytes = (size_t)width * height * 4 * sizeof(float);
+    PT_HIP_TRY(hipMalloc(&ctx->d_image[0], bytes));
+    ctx->image_owned = true;
+    PT_HIP_TRY(hipMalloc(&ctx->d_image[1], bytes));
+    s = target_common(ctx, width, height);
+    if (s != PT_OK) return s;
+    return pt_target_clear(ctx);
+}
+
+PtStatus pt_target_bind_external(PtContext* ctx, void* rgba_a, void* rgba_b, int32_t width, int32_t height) {
+    PtStatus s = bind(ctx);
+    if (s != PT_OK) return s;
+    PT_REQUIRE(rgba_a != nullptr && rgba_b != nullptr, PT_ERR_INVALID_ARGUMENT, "null image pointer");
+    PT_REQUIRE(((uintptr_t)rgba_a % 16) == 0 && ((uintptr_t)rgba_b % 16) == 0, PT_ERR_INVALID_ARGUMENT, "images must be 16-byte aligned");
+    PT_REQUIRE(width > 0 && height > 0 && width <= 65536 && height <= 65536, PT_ERR_INVALID_ARGUMENT, "bad target size %dx%d", width, height);
+    PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    free_target(ctx);
+    ctx->d_image[0] = (float*)rgba_a;
+    ctx->d_image[1] = (float*)rgba_b;
+    ctx->image_owned = false;
+    return target_common(ctx, width, height);
+}
+
+PtStatus pt_target_clear(PtContext* ctx) {
+    PtStatus s = bind(ctx);
+    if (s != PT_OK) return s;
+    PT_REQUIRE(ctx->d_image[0] != nullptr, PT_ERR_STATE, "no accumulation target");
+    const size_t n = (size_t)ctx->width * ctx->height;
+    const float a = ctx->accum_mode == PT_ACCUM_MEAN ? 1.0f : 0.0f;
+    PT_HIP_TRY(pt_launch_fill_rgba(ctx->d_image[0], n, 0.f, 0.f, 0.f, a, ctx->stream));
+    if (ctx->d_image[1] != ctx->d_image[0]) PT_HIP_TRY(pt_launch_fill_rgba(ctx->d_image[1], n, 0.f, 0.f, 0.f, a, ctx->stream));
+    ctx->current = 0;
+    return PT_OK;
+}
+
+PtStatus pt_set_window(PtContext* ctx, int32_t x0, int32_t y0, int32_t w, int32_t h) {
+    PT_REQUIRE(ctx != nullptr, PT_ERR_INVALID_ARGUMENT, "null context");
+    PT_REQUIRE(ctx->d_image[0] != nullptr, PT_ERR_STATE, "no accumulation target");
+    if (w == 0 && h == 0) {
+        ctx->win[0] = 0; ctx->win[1] = 0; ctx->win[2] = ctx->width; ctx->win[3] = ctx->height;
+        return PT_OK;
+    }
+    PT_REQUIRE(x0 >= 0 && y0 >= 0 && w > 0 && h > 0 && x0 + w <= ctx->width && y0 + h <= ctx->height, PT_ERR_INVALID_ARGUMENT,
+               "window (%d,%d,%d,%d) outside the %dx%d target", x0, y0, w, h, ctx->width, ctx->height);
+    ctx->win[0] = x0; ctx->win[1] = y0; ctx->win[2] = w; ctx->win[3] = h;
+    return PT_OK;
+}
+
+PtStatus pt_set_accum_mode(PtContext* ctx, PtAccumMode mode) {
+    PT_REQUIRE(ctx != nullptr, PT_ERR_INVALID_ARGUMENT, "null context");
+    PT_REQUIRE(mode == PT_ACCUM_MEAN || mode == PT_ACCUM_SUM, PT_ERR_INVALID_ARGUMENT, "unknown accumulation mode %d", (int)mode);
+    ctx->accum_mode = mode;
+    return PT_OK;
+}
+
+PtStatus pt_set_uniforms(PtContext* ctx, const PtUniforms* uniforms) {
+    PT_REQUIRE(ctx != nullptr && uniforms != nullptr, PT_ERR_INVALID_ARGUMENT, "null argument");
+    PT_REQUIRE(uniforms->num_triangles >= 0, PT_ERR_INVALID_ARGUMENT, "negative u_NumTriangles");
+    ctx->uniforms = *uniforms;
+    ctx->have_uniforms = true;
+    return PT_OK;
+}
+
+PtStatus pt_dispatch(PtContext* ctx, int32_t first_sample, int32_t num_samples, int32_t stride) {
+    PtStatus s = bind(ctx);
+    if (s != PT_OK) return s;
+    PT_REQUIRE(first_sample >= 1, PT_ERR_INVALID_ARGUMENT, "first_sample is 1-based; got %d", first_sample);
+    PT_REQUIRE(num_samples >= 1 && stride >= 1, PT_ERR_INVALID_ARGUMENT, "num_samples and stride must be >= 1");
+    // u_Samples is a float: beyond 2^24 consecutive indices stop being representable.
+    PT_REQUIRE((int64_t)first_sample + (int64_t)(num_samples - 1) * stride <= (1 << 24), PT_ERR_INVALID_ARGUMENT,
+               "sample index exceeds 2^24 (u_Samples is a float)");
+    PtKernelParams p;
+    const Program* prog = nullptr;
+    s = fill_params(ctx, &p, &prog);
+    if (s != PT_OK) return s;
+    p.first_sample = first_sample;
+    p.num_samples = num_samples;
+    p.sample_stride = stride;
+    // PathTracer.cpp:1384,1398: write fbo[current], read tex[current ^ 1]
+    p.dst = ctx->d_image[ctx->current];
+    p.src = ctx->d_image[ctx->current ^ 1];
+    // A pass only rewrites the window; with two distinct images the pixels outside it must follow the swap.
+    const bool partial = ctx->win[2] != ctx->width || ctx->win[3] != ctx->height;
+    if (partial && p.dst != p.src) {
+        PT_HIP_TRY(hipMemcpyAsync(p.dst, p.src, (size_t)ctx->width * ctx->height * 16, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    if (ctx->timing) {
+        s = collect_timing(ctx);
+        if (s != PT_OK) return s;
+        PT_HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
+    }
+    PT_HIP_TRY(pt_launch_render(p, (int)prog->kind, ctx->stream));
+    if (ctx->timing) {
+        PT_HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
+        ctx->ev_pending = true;
+    }
+    ctx->current ^= 1;  // PathTracer.cpp:1493
+    ctx->samples += (uint64_t)ctx->win[2] * ctx->win[3] * (uint64_t)num_samples;
+    ctx->dispatches += 1;
+    return PT_OK;
+}
+
+PtStatus pt_finish(PtContext* ctx) {
+    PtStatus s = bind(ctx);
+    if (s != PT_OK) return s;
+    PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    PT_HIP_TRY(hipGetLastError());
+    return collect_timing(ctx);
+}
+
+PtStatus pt_readback_rgba32f(PtContext* ctx, float* dst) {
+    PtStatus s = bind(ctx);
+    if (s != PT_OK) return s;
+    PT_REQUIRE(dst != nullptr, PT_ERR_INVALID_ARGUMENT, "dst is null");
+    PT_REQUIRE(ctx->d_image[0] != nullptr, PT_ERR_STATE, "no accumulation target");
+    const float* img = ctx->d_image[ctx->current ^ 1];
+    PT_HIP_TRY(hipMemcpyAsync(dst, img, (size_t)ctx->width * ctx->height * 16, hipMemcpyDeviceToHost, ctx->stream));
+    PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+PtStatus pt_current_image(PtContext* ctx, void** out_device_ptr) {
+    PT_REQUIRE(ctx != nullptr && out_device_ptr != nullptr, PT_ERR_INVALID_ARGUMENT, "null argument");
+    PT_REQUIRE(ctx->d_image[0] != nullptr, PT_ERR_STATE, "no accumulation target");
+    *out_device_ptr = ctx->d_image[ctx->current ^ 1];
+    return PT_OK;
+}
+
+PtStatus pt_readback_primary(PtContext* ctx, int32_t* ids, float* t) {
+    PtStatus s = bind(ctx);
+    if (s != PT_OK) return s;
+    PtKernelParams p;
+    const Program* prog = nullptr;
+    s = fill_params(ctx, &p, &prog);
+    if (s != PT_OK) return s;
+    p.out_ids = ctx->d_ids;
+    p.out_t = ctx->d_t;
+    const size_t n = (size_t)ctx->width * ctx->height;
+    // pixels outside the window report a miss
+    PT_HIP_TRY(hipMemsetAsync(ctx->d_ids, 0xff, n * sizeof(int32_t), ctx->stream));
+    PT_HIP_TRY(hipMemsetAsync(ctx->d_t, 0, n * sizeof(float), ctx->stream));
+    PT_HIP_TRY(pt_launch_primary(p, (int)prog->kind, ctx->stream));
+    if (ids) PT_HIP_TRY(hipMemcpyAsync(ids, ctx->d_ids, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (t) PT_HIP_TRY(hipMemcpyAsync(t, ctx->d_t, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+PtStatus pt_enable_timing(PtContext* ctx, int32_t enabled) {
+    PtStatus s = bind(ctx);
+    if (s != PT_OK) return s;
+    s = collect_timing(ctx);
+    if (s != PT_OK) return s;
+    ctx->timing = enabled != 0;
+    return PT_OK;
+}
+
+PtStatus pt_get_stats(PtContext* ctx, PtStats* out) {
+    PtStatus s = bind(ctx);
+    if (s != PT_OK) return s;
+    PT_REQUIRE(out != nullptr, PT_ERR_INVALID_ARGUMENT, "out is null");
+    PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    s = collect_timing(ctx);
+    if (s != PT_OK) return s;
+    unsigned long long c[2] = {0, 0};
+    PT_HIP_TRY(hipMemcpyAsync(c, ctx->d_counters, sizeof c, hipMemcpyDeviceToHost, ctx->stream));
+    PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    out->rays = c[0];
+    out->samples = ctx->samples;
+    out->dispatches = ctx->dispatches;
+    out->last_dispatch_ms = ctx->last_ms;
+    out->total_dispatch_ms = ctx->total_ms;
+    return PT_OK;
+}
+
+PtStatus pt_reset_stats(PtContext* ctx) {
+    PtStatus s = bind(ctx);
+    if (s != PT_OK) return s;
+    PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    s = collect_timing(ctx);
+    if (s != PT_OK) return s;
+    PT_HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->samples = 0;
+    ctx->dispatches = 0;
+    ctx->last_ms = 0.f;
+    ctx->total_ms = 0.0;
+    return PT_OK;
+}
+
+}  // extern "C"
+#pragma GCC visibility pop

@@ -1,0 +1,46 @@
+// Internal declarations shared by the kernels (pt_kernels.hip) and the C ABI (pt_capi.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// One record per triangle, 16 floats = 64 bytes, 64-byte aligned so that a wave fetches it with a single
+// scalar load (the record address is the same for every lane). Everything in it depends only on the triangle
+// and on the ray origin, and the origin is the camera position for EVERY ray of the reference shader (its
+// Shade() never moves `ro`, pathtracing.fs:224,262,274), so the per-ray work of pathtracing.fs:136-160 that
+// does not involve the ray direction is done once per triangle when the mesh or the camera changes:
+//   e1 = b - a, e2 = c - a                (pathtracing.fs:136-137)
+//   ap = ro - a, r = cross(ap, e1)        (pathtracing.fs:144-145)
+//   e2r = dot(e2, r)                      (numerator of pathtracing.fs:160)
+// The values are produced by the same fp32 operations in the same order, so results are bit-identical.
+#define PT_TRI_FLOATS 16
+struct PtTriRecordLayout {
+    enum { E1 = 0, E2 = 3, AP = 6, R = 9, E2R = 12 };
+};
+
+struct PtKernelParams {
+    float ro[3], llc[3], hor[3], ver[3];
+    int32_t width, height;              // full frame: textureSize(u_Texture, 0)
+    int32_t win_x0, win_y0, win_w, win_h;
+    int32_t num_triangles, depth;
+    int32_t first_sample, num_samples, sample_stride;
+    int32_t accum_mode;                 // PtAccumMode
+    int32_t normal_mode;                // PtNormalMode
+    const float* tris;                  // num_triangles x PT_TRI_FLOATS
+    const float* vnormals;              // num_triangles x 9: the three vertex normals (na, nb, nc)
+    const float* gnormals;              // num_triangles x 3: normalize(cross(e1, e2))
+    const float* spheres;               // 10 x (cx, cy, cz, r)
+    const float* src;                   // RGBA32F image read (previous result)
+    float* dst;                         // RGBA32F image written
+    unsigned long long* counters;       // [0] rays, [1] samples
+    int32_t* out_ids;                   // primary pass only
+    float* out_t;                       // primary pass only
+};
+
+// Launchers (defined in pt_kernels.hip). All are asynchronous on `stream`.
+hipError_t pt_launch_prepare_triangles(const float* vertices, const uint32_t* indices, int32_t num_triangles,
+                                       const float ro[3], float* tris, float* vnormals, float* gnormals,
+                                       hipStream_t stream);
+hipError_t pt_launch_fill_rgba(float* img, size_t num_pixels, float r, float g, float b, float a, hipStream_t stream);
+hipError_t pt_launch_render(const PtKernelParams& p, int program_kind, hipStream_t stream);
+hipError_t pt_launch_primary(const PtKernelParams& p, int program_kind, hipStream_t stream);

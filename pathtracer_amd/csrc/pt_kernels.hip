@@ -1,0 +1,389 @@
+// HIP kernels for gfx950 (MI355X): everything the reference's fragment shader data/shaders/pathtracing.fs
+// ("fs" below) does per pixel. Build flags matter and are part of the numerics contract (see build.py):
+//   -ffp-contract=off                 a*b+c is two roundings unless written as __builtin_fmaf
+//   -fgpu-flush-denormals-to-zero     the reference's software GL runs with FTZ+DAZ
+//   (default) correctly rounded fp32 divide and sqrt
+//
+// Execution shape: one lane owns one pixel for the whole dispatch and walks through its samples and bounces in
+// a single flattened loop whose trip = one closest-hit query ("ray"). A lane whose path ends (miss, depth limit)
+// folds the sample into its running mean and starts its next sample in the same iteration, so the lanes of a
+// wave stay busy although paths have different lengths; the running mean lives in registers and the image is
+// read once and written once per dispatch, not once per sample. Triangle records are wave-uniform: the loop
+// over triangles fetches each 64-byte record with scalar loads and every lane tests its own ray against it.
+#include "pt_internal.h"
+
+namespace {
+
+struct v3 { float x, y, z; };
+
+__device__ __forceinline__ v3 V(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ v3 operator+(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ v3 operator-(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ v3 operator*(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
+// GLSL built-ins in the evaluation order of the reference's software GL:
+//   dot(a,b) = a.x*b.x + (a.y*b.y + a.z*b.z);  normalize(v) = v * (1/sqrt(dot(v,v)));  reflect(I,N) = I - (2 dot(N,I)) N
+__device__ __forceinline__ float dot3(v3 a, v3 b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
+__device__ __forceinline__ v3 cross3(v3 a, v3 b) {
+    return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ v3 normalize3(v3 a) { return a * (1.0f / __builtin_sqrtf(dot3(a, a))); }
+__device__ __forceinline__ v3 reflect3(v3 i, v3 n) { return i - n * (2.0f * dot3(n, i)); }
+__device__ __forceinline__ float fract1(float x) { return x - __builtin_floorf(x); }
+__device__ __forceinline__ float clamp01(float x) { return __builtin_fminf(__builtin_fmaxf(x, 0.0f), 1.0f); }
+
+// ---- sin / cos / exp2 / pow in the polynomial forms the reference's software GL uses ------------------------
+// Range reduction by multiples of pi/4 with a three-part constant, then a degree-3 polynomial in x^2 for the
+// sine or the cosine octant; fused multiply-adds exactly where written.
+template <bool COS>
+__device__ __forceinline__ float lp_sincos(float a) {
+    const uint32_t ai = __float_as_uint(a);
+    const float x_abs = __uint_as_float(ai & 0x7fffffffu);
+    const float scale_y = x_abs * 1.27323954473516f;
+    const int32_t j1 = (int32_t)scale_y + 1;
+    const int32_t je = j1 & ~1;
+    const float y = (float)je;
+    const int32_t sel = COS ? je - 2 : je;
+    const uint32_t sign = COS ? (((uint32_t)(4 & ~sel)) << 29) : ((ai ^ ((uint32_t)j1 << 29)) & 0x80000000u);
+    float x = __builtin_fmaf(y, -0.78515625f, x_abs);
+    x = __builtin_fmaf(y, -2.4187564849853515625e-4f, x);
+    x = __builtin_fmaf(y, -3.77489497744594108e-8f, x);
+    const float z = x * x;
+    float c = __builtin_fmaf(z, 2.443315711809948E-005f, -1.388731625493765E-003f);
+    c = __builtin_fmaf(c, z, 4.166664568298827E-002f);
+    c = c * z;
+    c = c * z;
+    c = c - z * 0.5f;
+    c = c + 1.0f;
+    float s = __builtin_fmaf(z, -1.9515295891E-4f, 8.3321608736E-3f);
+    s = __builtin_fmaf(s, z, -1.6666654611E-1f);
+    s = s * z;
+    s = __builtin_fmaf(s, x, x);
+    const float r = __uint_as_float(__float_as_uint((sel & 2) == 0 ? s : c) ^ sign);
+    return __builtin_fminf(__builtin_fmaxf(r, -1.0f), 1.0f);
+}
+
+// exp2: split into floor and fraction, degree-5 polynomial on the fraction evaluated as even/odd Horner chains.
+__device__ __forceinline__ float lp_exp2(float x) {
+    x = __builtin_fminf(128.0f, x);
+    x = __builtin_fmaxf(-126.99999f, x);
+    const float ip = __builtin_floorf(x);
+    const float f = x - ip;
+    const float e = __uint_as_float((uint32_t)(((int32_t)ip + 127) << 23));
+    const float f2 = f * f;
+    float even = __builtin_fmaf(f2, 0.00898934009049466391101f, 0.240153617044375388211f);
+    even = __builtin_fmaf(f2, even, 1.0f);
+    float odd = __builtin_fmaf(f2, 0.00187757667519147912699f, 0.0558263180532956664775f);
+    odd = __builtin_fmaf(f2, odd, 0.693153073200168932794f);
+    return e * __builtin_fmaf(odd, f, even);
+}
+
+// log2: exponent + y*P(y^2) with y = (m-1)/(m+1), m the mantissa in [1,2); degree-4 P.
+__device__ __forceinline__ float lp_log2(float x) {
+    const uint32_t i = __float_as_uint(x);
+    const float e = (float)((int32_t)((i & 0x7f800000u) >> 23) - 127);
+    const float m = __uint_as_float((i & 0x007fffffu) | 0x3f800000u);
+    const float y = (m - 1.0f) / (m + 1.0f);
+    const float z = y * y;
+    const float z2 = z * z;
+    float even = __builtin_fmaf(z2, 0.406718052498846252698f, 0.577440339438736392009f);
+    even = __builtin_fmaf(z2, even, 2.88539009343309178325f);
+    float odd = __builtin_fmaf(z2, 0.403343858251329912514f, 0.961791550404184197881f);
+    float r = __builtin_fmaf(y, __builtin_fmaf(odd, z, even), e);
+    if (x >= __builtin_inff()) r = __builtin_inff();
+    if (x == 0.0f) r = -__builtin_inff();
+    if (x < 0.0f) r = __builtin_nanf("");
+    return r;
+}
+__device__ __forceinline__ float lp_pow(float x, float y) { return lp_exp2(lp_log2(x) * y); }
+
+// ---- the shader's random numbers (fs:21-42) -------------------------------------------------------------
+struct Rng {
+    float fcx, fcy;  // gl_FragCoord.xy
+    float samples;   // u_Samples
+    float sx;        // randState.x (randState.y is written by the shader but never read)
+    // fs:27-36, then mod(r, 1.0) = r - floor(r) (fs:41)
+    __device__ __forceinline__ float rand01() {
+        const float ax = (fcx + sx) + samples;
+        const float ay = (fcy + sx) + samples;
+        const float r = fract1(52.9829189f * fract1(ax * 0.06711056f + ay * 0.00583715f));
+        sx = sx + r;
+        return r - __builtin_floorf(r);
+    }
+};
+
+struct Hit {
+    float t;    // recT; 1e38 when nothing was hit
+    int id;     // -1 = miss
+    float u, v, ood;  // mesh only: the two barycentric numerators and 1/det of the accepted triangle
+};
+
+// fs:125-174 with the direction-independent parts taken from the triangle record (see pt_internal.h).
+// The record address is wave-uniform, so the compiler fetches it with scalar loads.
+__device__ __forceinline__ Hit intersect_mesh(const float* __restrict__ tris, int n, v3 rd) {
+    Hit h;
+    h.t = 1.0e38f; h.id = -1; h.u = 0.f; h.v = 0.f; h.ood = 0.f;
+    for (int i = 0; i < n; ++i) {
+        const float* __restrict__ rec = tris + (size_t)i * PT_TRI_FLOATS;
+        const v3 e1 = V(rec[0], rec[1], rec[2]);
+        const v3 e2 = V(rec[3], rec[4], rec[5]);
+        const v3 ap = V(rec[6], rec[7], rec[8]);
+        const v3 r = V(rec[9], rec[10], rec[11]);
+        const float e2r = rec[12];
+        const v3 q = cross3(rd, e2);
+        const float det = dot3(e1, q);
+        const float u = dot3(ap, q);
+        const float v = dot3(rd, r);
+        const bool inside = (det >= 0.0001f) & (u >= 0.0f) & (u <= det) & (v >= 0.0f) & ((u + v) <= det);
+        if (inside) {
+            const float ood = 1.0f / det;
+            const float t = e2r * ood;
+            if (t > 0.0f && t < h.t) {  // strict '<' in ascending i: the lowest index wins ties
+                h.t = t; h.id = i; h.u = u; h.v = v; h.ood = ood;
+            }
+        }
+    }
+    return h;
+}
+
+// fs:83-121. `ro` is the camera position for every ray. Returns the hit normal through `n`.
+__device__ __forceinline__ Hit intersect_world(const float* __restrict__ spheres, v3 ro, v3 rd, v3& n) {
+    Hit h;
+    h.t = 1.0e38f; h.id = -1; h.u = 0.f; h.v = 0.f; h.ood = 0.f;
+#pragma unroll
+    for (int obj = 0; obj < 10; ++obj) {
+        const v3 center = V(spheres[4 * obj], spheres[4 * obj + 1], spheres[4 * obj + 2]);
+        const float radius = spheres[4 * obj + 3];
+        const v3 to = ro - center;
+        const float B = -dot3(to, rd);
+        const float C = dot3(to, to) - radius * radius;
+        const float disc = B * B - C;
+        if (disc > 0.0f) {
+            const float root = __builtin_sqrtf(disc);
+            float temp = B - root;
+            temp = temp > 0.0f ? temp : (B + root);
+            if (temp > 0.0f && temp < h.t) {
+                const v3 p = ro + rd * temp;
+                n = (p - center) * (1.0f / radius);
+                h.t = temp; h.id = obj;
+            }
+        }
+    }
+    return h;
+}
+
+// Shading normal of a mesh hit, computed once for the accepted triangle (fs:164-166).
+__device__ __forceinline__ v3 mesh_normal(const PtKernelParams& p, const Hit& h) {
+    if (p.normal_mode == 0) {
+        const float* __restrict__ nn = p.vnormals + (size_t)h.id * 9;
+        const float ux = h.u * h.ood, uy = h.v * h.ood, uz = (1.0f - ux) - uy;
+        const v3 na = V(nn[0], nn[1], nn[2]), nb = V(nn[3], nn[4], nn[5]), nc = V(nn[6], nn[7], nn[8]);
+        return normalize3((na * uz + nb * ux) + nc * uy);
+    }
+    const float* __restrict__ g = p.gnormals + (size_t)h.id * 3;
+    return V(g[0], g[1], g[2]);
+}
+
+// fs:224-361, the lines that are live: modified-Phong lobe about the mirror direction, specularity 0.94,
+// exponent 1024, albedo 0.5. Replaces rd and scales the (grey) path throughput; `ro` is never moved.
+__device__ __forceinline__ void shade(Rng& rng, float& energy, v3& rd, v3 N) {
+    const float specularity = 0.94f;
+    const float alpha = 1024.0f;
+    const v3 R = reflect3(rd, N);
+    const float r1 = rng.rand01();
+    // GetTangentSpace(R), fs:44-55
+    v3 helper = V(1.0f, 0.0f, 0.0f);
+    if (__builtin_fabsf(R.x) > 0.99f) helper = V(0.0f, 0.0f, 1.0f);
+    const v3 tangent = normalize3(cross3(R, helper));
+    const v3 binormal = normalize3(cross3(R, tangent));
+    // randomHemisphere(r1, alpha), fs:67-76
+    const float cos_t = lp_pow(r1, 1.0f / (alpha + 1.0f));
+    const float sin_t = __builtin_sqrtf(__builtin_fmaxf(0.0f, 1.0f - cos_t * cos_t));
+    const float phi = (rng.rand01() * 2.0f) * 3.141592653589f;
+    const v3 hemi = V(lp_sincos<true>(phi) * sin_t, cos_t, lp_sincos<false>(phi) * sin_t);
+    // mat3(tangent, R, binormal) * hemi = (c0*x + c1*y) + c2*z
+    rd = (tangent * hemi.x + R * hemi.y) + binormal * hemi.z;
+    const float diffuse = __builtin_fminf(1.0f - specularity, 0.5f);
+    const float f = (alpha + 2.0f) / (alpha + 1.0f);
+    const float fresnel = specularity + (1.0f - specularity) * lp_exp2(-8.656170f * clamp01(dot3(N, rd)));
+    const float specular = (fresnel * specularity) * clamp01(dot3(N, rd) * f);
+    energy = energy * (diffuse + specular);
+}
+
+__device__ __forceinline__ bool pixel_of_lane(const PtKernelParams& p, int& x, int& y) {
+    // 256 threads = 4 waves; a wave covers an 8x8 pixel tile, the block a 16x16 tile.
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lx = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int ly = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    x = p.win_x0 + lx;
+    y = p.win_y0 + ly;
+    return lx < p.win_w && ly < p.win_h;
+}
+
+// fs:381-383
+__device__ __forceinline__ v3 primary_direction(const PtKernelParams& p, float fcx, float fcy) {
+    const float ijx = fcx / (float)p.width, ijy = fcy / (float)p.height;
+    const v3 ro = V(p.ro[0], p.ro[1], p.ro[2]);
+    const v3 llc = V(p.llc[0], p.llc[1], p.llc[2]);
+    const v3 hor = V(p.hor[0], p.hor[1], p.hor[2]);
+    const v3 ver = V(p.ver[0], p.ver[1], p.ver[2]);
+    return normalize3(((llc + hor * ijx) + ver * ijy) - ro);
+}
+
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <int KIND>  // PtProgramKind
+__global__ __launch_bounds__(256) void pt_render_kernel(const PtKernelParams p) {
+    int x, y;
+    const bool in_window = pixel_of_lane(p, x, y);
+    const size_t pix = in_window ? ((size_t)y * p.width + x) : 0;
+    const v3 ro = V(p.ro[0], p.ro[1], p.ro[2]);
+
+    Rng rng;
+    rng.fcx = (float)x + 0.5f;
+    rng.fcy = (float)y + 0.5f;
+    const v3 rd0 = primary_direction(p, rng.fcx, rng.fcy);
+
+    float4 prev = make_float4(0.f, 0.f, 0.f, 1.f);
+    if (in_window) prev = reinterpret_cast<const float4*>(p.src)[pix];
+    float mr = prev.x, mg = prev.y, mb = prev.z;
+
+    int remaining = in_window ? p.num_samples : 0;
+    int sample = p.first_sample;
+    unsigned rays = 0;
+
+    // path state
+    v3 rd = rd0;
+    float energy = 1.0f;
+    int level = 0;
+    rng.samples = (float)sample;
+    rng.sx = 0.0f;
+
+    while (remaining > 0) {
+        Hit h;
+        v3 N = V(0.f, 0.f, 0.f);
+        if (KIND == 0) h = intersect_world(p.spheres, ro, rd, N);
+        else h = intersect_mesh(p.tris, p.num_triangles, rd);
+        ++rays;
+        const bool hit = h.id >= 0;
+        if (hit) {
+            if (KIND != 0) N = mesh_normal(p, h);
+            shade(rng, energy, rd, N);
+        }
+        ++level;
+        // fs:402 and the loop bound fs:388
+        if (!hit || energy == 0.0f || level >= p.depth) {
+            // fs:408-415
+            const float t = 0.5f * (rd.y + 1.0f);
+            const float omt = 1.0f - t;
+            const float sr = energy * (omt + 0.5f * t), sg = energy * (omt + 0.7f * t), sb = energy * (omt + 1.0f * t);
+            if (p.accum_mode == 0) {
+                const float a = 1.0f / rng.samples;
+                mr = mr + a * (sr - mr);
+                mg = mg + a * (sg - mg);
+                mb = mb + a * (sb - mb);
+            } else {
+                mr += sr; mg += sg; mb += sb;
+            }
+            --remaining;
+            sample += p.sample_stride;
+            rd = rd0; energy = 1.0f; level = 0;
+            rng.samples = (float)sample;
+            rng.sx = 0.0f;
+        }
+    }
+    if (in_window) {
+        const float alpha = p.accum_mode == 0 ? 1.0f : prev.w + (float)p.num_samples;
+        reinterpret_cast<float4*>(p.dst)[pix] = make_float4(mr, mg, mb, alpha);
+    }
+    const unsigned long long wave_rays = wave_sum(rays);
+    if ((threadIdx.x & 63) == 0 && wave_rays) atomicAdd(&p.counters[0], wave_rays);
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void pt_primary_kernel(const PtKernelParams p) {
+    int x, y;
+    if (!pixel_of_lane(p, x, y)) return;
+    const size_t pix = (size_t)y * p.width + x;
+    const v3 ro = V(p.ro[0], p.ro[1], p.ro[2]);
+    const v3 rd = primary_direction(p, (float)x + 0.5f, (float)y + 0.5f);
+    Hit h;
+    v3 N;
+    if (KIND == 0) h = intersect_world(p.spheres, ro, rd, N);
+    else h = intersect_mesh(p.tris, p.num_triangles, rd);
+    if (p.out_ids) p.out_ids[pix] = h.id;
+    if (p.out_t) p.out_t[pix] = h.t;
+}
+
+// One thread per triangle: gathers the three vertices through the index buffer and writes the SoA records.
+__global__ __launch_bounds__(256) void pt_prepare_triangles_kernel(const float* __restrict__ vertices,
+                                                                    const uint32_t* __restrict__ indices, int n,
+                                                                    float rox, float roy, float roz,
+                                                                    float* __restrict__ tris, float* __restrict__ vnormals,
+                                                                    float* __restrict__ gnormals) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* pa = vertices + 6 * (size_t)indices[3 * i];
+    const float* pb = vertices + 6 * (size_t)indices[3 * i + 1];
+    const float* pc = vertices + 6 * (size_t)indices[3 * i + 2];
+    const v3 a = V(pa[0], pa[1], pa[2]), b = V(pb[0], pb[1], pb[2]), c = V(pc[0], pc[1], pc[2]);
+    const v3 e1 = b - a, e2 = c - a;
+    const v3 ap = V(rox, roy, roz) - a;
+    const v3 r = cross3(ap, e1);
+    float* t = tris + (size_t)i * PT_TRI_FLOATS;
+    t[0] = e1.x; t[1] = e1.y; t[2] = e1.z;
+    t[3] = e2.x; t[4] = e2.y; t[5] = e2.z;
+    t[6] = ap.x; t[7] = ap.y; t[8] = ap.z;
+    t[9] = r.x; t[10] = r.y; t[11] = r.z;
+    t[12] = dot3(e2, r);
+    t[13] = 0.f; t[14] = 0.f; t[15] = 0.f;
+    float* vn = vnormals + (size_t)i * 9;
+    vn[0] = pa[3]; vn[1] = pa[4]; vn[2] = pa[5];
+    vn[3] = pb[3]; vn[4] = pb[4]; vn[5] = pb[5];
+    vn[6] = pc[3]; vn[7] = pc[4]; vn[8] = pc[5];
+    const v3 g = normalize3(cross3(e1, e2));
+    gnormals[3 * (size_t)i] = g.x; gnormals[3 * (size_t)i + 1] = g.y; gnormals[3 * (size_t)i + 2] = g.z;
+}
+
+__global__ __launch_bounds__(256) void pt_fill_rgba_kernel(float4* img, size_t n, float4 value) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) img[i] = value;
+}
+
+dim3 window_grid(const PtKernelParams& p) { return dim3((p.win_w + 15) / 16, (p.win_h + 15) / 16, 1); }
+
+}  // namespace
+
+hipError_t pt_launch_prepare_triangles(const float* vertices, const uint32_t* indices, int32_t num_triangles,
+                                       const float ro[3], float* tris, float* vnormals, float* gnormals,
+                                       hipStream_t stream) {
+    if (num_triangles <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pt_prepare_triangles_kernel, dim3((num_triangles + 255) / 256), dim3(256), 0, stream, vertices,
+                       indices, num_triangles, ro[0], ro[1], ro[2], tris, vnormals, gnormals);
+    return hipGetLastError();
+}
+
+hipError_t pt_launch_fill_rgba(float* img, size_t num_pixels, float r, float g, float b, float a, hipStream_t stream) {
+    if (num_pixels == 0) return hipSuccess;
+    const size_t blocks = (num_pixels + 255) / 256;
+    hipLaunchKernelGGL(pt_fill_rgba_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream,
+                       reinterpret_cast<float4*>(img), num_pixels, make_float4(r, g, b, a));
+    return hipGetLastError();
+}
+
+hipError_t pt_launch_render(const PtKernelParams& p, int program_kind, hipStream_t stream) {
+    if (p.win_w <= 0 || p.win_h <= 0 || p.num_samples <= 0) return hipSuccess;
+    if (program_kind == 0) hipLaunchKernelGGL(pt_render_kernel<0>, window_grid(p), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(pt_render_kernel<1>, window_grid(p), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t pt_launch_primary(const PtKernelParams& p, int program_kind, hipStream_t stream) {
+    if (p.win_w <= 0 || p.win_h <= 0) return hipSuccess;
+    if (program_kind == 0) hipLaunchKernelGGL(pt_primary_kernel<0>, window_grid(p), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(pt_primary_kernel<1>, window_grid(p), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
