@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Throughput of the hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A step = one pass of the hot path over one batch: `--spp` progressive samples of every pixel of the workload's frame
+(default: cornell_box.obj at 1920x1080, 256 spp -- the configuration the metric is quoted on), rendered by ONE kernel
+launch with the scene and the accumulation image resident in HBM. With N > 1 every rank renders its own residue
+class of the sample indices (weak scaling: per-GPU work is fixed) into a running sum, and the sums are merged by one
+RCCL all-reduce per step inside the timed region.
+
+Prints one JSON line on rank 0: whole-job Mrays/s (ray = one closest-hit query = one bounce-loop iteration, the
+reference's definition), the roofline of the render kernel and a CPU baseline from the oracle on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# fp32 vector peak of the part (MI355X_MICROARCH.md): 256 CUs x 4 SIMD x 32 lanes x 2.4 GHz x 2 flop (FMA).
+PEAK_FP32_VALU_TFLOPS = 157.3
+# The numerics contract forbids fusing a*b+c (the reference's software GL does not fuse), so a multiply and an add
+# are two instructions: the ceiling for THIS arithmetic is half the FMA peak.
+PEAK_FP32_UNFUSED_TFLOPS = PEAK_FP32_VALU_TFLOPS / 2
+# Algorithmic work of one ray-triangle test as the shader writes it (pathtracing.fs:136-151): 43 flop, mul and add
+# counted separately; flop per ray = 43 x triangles.
+FLOP_PER_TRI_TEST = 43
+
+
+def cpu_baseline(scene, spp_hint, budget_s=12.0):
+    """The oracle (CPU restatement of the reference shader) on the same scene/camera/resolution, on a bounded sample:
+    the full frame for as many passes as fit the time budget."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pt_oracle as po
+    threads = min(16, os.cpu_count() or 1)
+    sc = po.Scene(scene.vertices, scene.indices, scene.spheres, scene.materials)
+    u = po.uniforms(scene.camera, scene.width, scene.height, scene.num_triangles, 10,
+                    po.VARIANT_MESH if scene.program == 1 else po.VARIANT_WORLD, scene.normal_mode)
+    # calibrate on a strip, then run whole-frame passes within the budget
+    strip = max(8, scene.height // 16)
+    t0 = time.perf_counter()
+    _, rays = po.render(sc, u, 1, 1, window=(0, (scene.height - strip) // 2, scene.width, strip), threads=threads)
+    dt = time.perf_counter() - t0
+    per_pass = dt * scene.height / strip
+    passes = int(max(1, min(spp_hint, budget_s / max(per_pass, 1e-6))))
+    t0 = time.perf_counter()
+    _, rays = po.render(sc, u, 1, passes, threads=threads)
+    dt = time.perf_counter() - t0
+    return {"value": rays / dt * 1e-6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"{scene.name} {scene.width}x{scene.height}, passes 1..{passes} of the full frame, "
+                      f"{rays} rays in {dt:.2f} s (oracle/pt_oracle.c, {threads} threads)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cornell")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--spp", type=int, default=256, help="samples per pixel per step and per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from pathtracer_amd import Tracer, capi, dist as ptdist
+    from pathtracer_amd.scenes import SceneData
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    scene = SceneData(args.workload, args.width, args.height)
+    W, H, spp = scene.width, scene.height, args.spp
+    tracer = Tracer(local_rank)
+    stream = torch.cuda.Stream(device=device)
+    tracer.set_stream(stream.cuda_stream)
+    scene.upload(tracer)
+    # the accumulation image lives in a torch tensor so that RCCL can reduce it in place
+    image = torch.zeros((H, W, 4), dtype=torch.float32, device=device)
+    tracer.target_bind_external(image.data_ptr(), image.data_ptr(), W, H)
+    sample_split = world > 1
+    tracer.set_accum_mode(capi.ACCUM_SUM if sample_split else capi.ACCUM_MEAN)
+    first, stride, count = ptdist.sample_indices(rank, world, spp * world)
+    tracer.enable_timing(True)
+
+    def step():
+        with torch.cuda.stream(stream):
+            image.zero_()
+            if not sample_split:
+                image[..., 3] = 1.0
+            tracer.dispatch(first, count, stride)
+            if sample_split:
+                ptdist.merge_sample_split(image, spp * world)
+
+    def fence():
+        stream.synchronize()
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    tracer.reset_stats()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    st = tracer.stats()
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    counts = torch.tensor([float(st["rays"]), float(st["samples"])], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    elapsed = float(t.item())
+    rays, samples = float(counts[0].item()), float(counts[1].item())
+
+    if rank == 0:
+        kernel_ms = st["total_dispatch_ms"] / max(1, st["dispatches"])
+        rays_per_launch = st["rays"] / max(1, st["dispatches"])
+        flop_per_launch = rays_per_launch * FLOP_PER_TRI_TEST * scene.num_triangles
+        achieved = flop_per_launch / (kernel_ms * 1e-3) * 1e-12 if kernel_ms > 0 else 0.0
+        out = {
+            "metric": "Mrays/s (whole node) at 1080p Cornell box + 1M-tri scene, 1/2/4/8 MI355X",
+            "value": rays / elapsed * 1e-6,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic camera on the reference's cornell_box.obj" if args.workload == "cornell" else "reference OBJ asset",
+            "config": {"workload": f"{scene.name} {W}x{H}, {spp} spp per GPU per step, depth 10, "
+                                   f"{scene.num_triangles} triangles, brute-force closest hit",
+                       "parallelism": "single GPU" if world == 1 else f"sample split over {world} GPUs + RCCL all-reduce"},
+            "samples_per_s": samples / elapsed,
+            "rays_per_sample": rays / samples if samples else 0.0,
+            "roofline": {
+                "bound": "valu",
+                "achieved": achieved,
+                "peak": PEAK_FP32_VALU_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP32_VALU_TFLOPS,
+                "peak_unfused": PEAK_FP32_UNFUSED_TFLOPS,
+                "frac_unfused": achieved / PEAK_FP32_UNFUSED_TFLOPS,
+                "traffic": None,
+                "kernel": "pt_render_kernel<mesh>" if scene.program == 1 else "pt_render_kernel<world>",
+                "kernel_ms": kernel_ms,
+                "algorithmic_flop_per_launch": flop_per_launch,
+                "note": "algorithmic flop = rays x 43 x triangles (mul and add counted separately; FMA is not permitted by "
+                        "the numerics contract); shading and RNG work is not counted",
+            },
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene, spp)
+        print(json.dumps(out), flush=True)
+
+    tracer.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

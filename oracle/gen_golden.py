@@ -24,6 +24,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 REF = os.environ.get("PT_REFERENCE", "/root/reference")
 GOLD = os.path.join(ROOT, "tests", "golden")
+ASSETS_DIR = os.path.join(ROOT, "assets")
 HARNESS = os.path.join(HERE, "_ref", "lp_harness")
 OBJDUMP = os.path.join(HERE, "_ref", "tinyobj_dump")
 EDITS = os.path.join(HERE, "llvmpipe", "edits")
@@ -199,22 +200,22 @@ def rng_fixture(scene):
 
 def main():
     os.makedirs(GOLD, exist_ok=True)
-    os.makedirs(f"{GOLD}/assets", exist_ok=True)
+    os.makedirs(ASSETS_DIR, exist_ok=True)
     report = []
 
     # ---- OBJ assets: data files copied verbatim (they are inputs), plus what the reference's parser returns
     objs = {}
     for a in ASSETS:
-        shutil.copyfile(f"{REF}/data/{a}.obj", f"{GOLD}/assets/{a}.obj")
-        os.chmod(f"{GOLD}/assets/{a}.obj", 0o644)
+        shutil.copyfile(f"{REF}/data/{a}.obj", f"{ASSETS_DIR}/{a}.obj")
+        os.chmod(f"{ASSETS_DIR}/{a}.obj", 0o644)
         d, info = run_obj_dump(a)
         objs[a] = d
         np.savez_compressed(f"{GOLD}/obj_{a}.npz", **d)
         report.append({"case": f"obj_{a}", **info})
         print(json.dumps(report[-1]))
     for m in ["cornell_box.mtl", "cube.mtl", "monkeyhead2.mtl"]:
-        shutil.copyfile(f"{REF}/data/{m}", f"{GOLD}/assets/{m}")
-        os.chmod(f"{GOLD}/assets/{m}", 0o644)
+        shutil.copyfile(f"{REF}/data/{m}", f"{ASSETS_DIR}/{m}")
+        os.chmod(f"{ASSETS_DIR}/{m}", 0o644)
 
     # ---- llvmpipe math + RNG known answers
     mf, rep = math_fixture()

@@ -67,14 +67,27 @@ def build_host(force=False):
         return None
     if not force and not _newer(out, srcs + hdrs + [os.path.join(ROOT, "include", "pt_hip.h"), __file__]):
         return out
-    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fvisibility=hidden", "-Wall", "-Wextra",
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall", "-Wextra",
            f"-I{os.path.join(ROOT, 'include')}", "-o", out] + srcs + [f"-L{LIB}", "-lpt_hip", "-Wl,-rpath,$ORIGIN"]
     _run(cmd)
     return out
 
 
+def build_cli(force=False):
+    """pathtracer_amd/lib/pt_render: headless counterpart of the reference executable."""
+    out = os.path.join(LIB, "pt_render")
+    src = os.path.join(HOST, "pt_render_main.cpp")
+    if not os.path.exists(src):
+        return None
+    if not force and not _newer(out, [src, os.path.join(LIB, "libpt_host.so")]):
+        return out
+    _run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", f"-I{os.path.join(ROOT, 'include')}", "-o", out, src,
+          f"-L{LIB}", "-lpt_host", "-lpt_hip", "-Wl,-rpath,$ORIGIN"])
+    return out
+
+
 def build_all(force=False):
-    return [build_hip(force), build_host(force)]
+    return [build_hip(force), build_host(force), build_cli(force)]
 
 
 if __name__ == "__main__":

@@ -1,0 +1,63 @@
+"""Multi-GPU partitions of the accumulation (one process per GPU, torch.distributed; backend "nccl" is RCCL over
+xGMI on the GPU box, "gloo" in CPU tests).
+
+Every (pixel, sample) is independent and the shader's random numbers are a pure function of pixel centre and sample
+index, so the work shards two ways with no exchange until the end:
+
+  sample split   rank r renders sample indices r+1, r+1+R, r+1+2R, ... with the TRUE index in the RNG and keeps a
+                 running fp32 SUM; one all-reduce(sum) of the image merges them and a scale by 1/N gives the mean.
+                 Differs from the sequential running mean only by fp32 rounding.
+  tile split     rank r owns a set of rows (interleaved blocks, for balance) and runs ALL samples for them with the
+                 reference recurrence, so its pixels are bit-identical to a 1-GPU render; the merge moves bytes only.
+
+The renderer is injected (`render_sum(first, stride, count)` / `render_rows(y0, h)`), so this module holds no
+tracing code: on the GPU box the callables wrap pathtracer_amd.Tracer, in CPU tests they wrap a checker.
+"""
+import torch
+import torch.distributed as dist
+
+
+def sample_indices(rank, world, total_samples):
+    """(first_sample, stride, count) of the 1-based sample indices rank `rank` renders out of 1..total_samples."""
+    if total_samples < 0 or not (0 <= rank < world):
+        raise ValueError("bad partition arguments")
+    count = (total_samples - rank + world - 1) // world if total_samples > rank else 0
+    return rank + 1, world, count
+
+
+def row_blocks(rank, world, height, block=16):
+    """Row ranges [(y0, h), ...] of rank `rank`: blocks of `block` rows dealt round-robin, so expensive image regions
+    are shared out. The union over ranks covers 0..height exactly once."""
+    if height < 0 or block <= 0 or not (0 <= rank < world):
+        raise ValueError("bad partition arguments")
+    out = []
+    for i, y0 in enumerate(range(0, height, block)):
+        if i % world == rank:
+            out.append((y0, min(block, height - y0)))
+    return out
+
+
+def merge_sample_split(sum_image, total_samples, group=None):
+    """In-place all-reduce of the per-rank running sums, then scale to the mean. `sum_image`: [H, W, 4] fp32 tensor
+    whose rgb holds this rank's sum; alpha is overwritten with 1."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(sum_image, op=dist.ReduceOp.SUM, group=group)
+    sum_image.mul_(1.0 / float(total_samples))
+    sum_image[..., 3] = 1.0
+    return sum_image
+
+
+def merge_tile_split(image, height, block=16, group=None):
+    """Every rank ends up with the full image: rows it does not own are zero before the call, so a sum all-reduce
+    moves each row from its owner to everyone without changing a bit (x + 0 + ... + 0 is exact)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(image, op=dist.ReduceOp.SUM, group=group)
+    return image
+
+
+def zero_unowned_rows(image, rank, world, block=16):
+    own = torch.zeros(image.shape[0], dtype=torch.bool, device=image.device)
+    for y0, h in row_blocks(rank, world, image.shape[0], block):
+        own[y0:y0 + h] = True
+    image[~own] = 0
+    return image

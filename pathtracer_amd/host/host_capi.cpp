@@ -1,0 +1,155 @@
+// C exports of the host library for tests, benchmarks and other-language callers. These are conveniences over the
+// C++ host classes (ObjLoader, Scene, Shader, RenderLoop); the reference-replacing device ABI is include/pt_hip.h.
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ObjLoader.h"
+#include "RenderLoop.h"
+#include "Scene.h"
+#include "Shader.h"
+
+#define PTH_API extern "C" __attribute__((visibility("default")))
+
+struct PthObj {
+    ptobj::attrib_t attrib;
+    std::vector<ptobj::shape_t> shapes;
+    std::vector<ptobj::material_t> materials;
+    std::string err;
+    size_t triangles = 0;
+};
+
+static void copy_text(char* dst, int cap, const std::string& s) {
+    if (!dst || cap <= 0) return;
+    const size_t n = s.size() < (size_t)cap - 1 ? s.size() : (size_t)cap - 1;
+    memcpy(dst, s.data(), n);
+    dst[n] = '\0';
+}
+
+PTH_API PthObj* pth_obj_load(const char* path, const char* mtl_basedir, char* err, int err_cap) {
+    PthObj* o = new PthObj();
+    const bool ok = ptobj::LoadObj(&o->attrib, &o->shapes, &o->materials, &o->err, path, mtl_basedir);
+    copy_text(err, err_cap, o->err);
+    if (!ok) {
+        delete o;
+        return nullptr;
+    }
+    for (auto& s : o->shapes) o->triangles += s.mesh.indices.size() / 3;
+    return o;
+}
+
+PTH_API void pth_obj_free(PthObj* o) { delete o; }
+
+// counts: positions, normals, triangles, shapes, materials
+PTH_API void pth_obj_counts(const PthObj* o, int* counts5) {
+    counts5[0] = (int)(o->attrib.vertices.size() / 3);
+    counts5[1] = (int)(o->attrib.normals.size() / 3);
+    counts5[2] = (int)o->triangles;
+    counts5[3] = (int)o->shapes.size();
+    counts5[4] = (int)o->materials.size();
+}
+
+// Any destination may be NULL. Index arrays hold 3 entries per triangle, all shapes concatenated in shape order.
+PTH_API void pth_obj_copy(const PthObj* o, float* v, float* vn, int* idx_v, int* idx_vn, int* mat_ids, int* shape_tris) {
+    if (v && !o->attrib.vertices.empty()) memcpy(v, o->attrib.vertices.data(), o->attrib.vertices.size() * 4);
+    if (vn && !o->attrib.normals.empty()) memcpy(vn, o->attrib.normals.data(), o->attrib.normals.size() * 4);
+    size_t k = 0, t = 0, si = 0;
+    for (auto& s : o->shapes) {
+        for (auto& i : s.mesh.indices) {
+            if (idx_v) idx_v[k] = i.vertex_index;
+            if (idx_vn) idx_vn[k] = i.normal_index;
+            ++k;
+        }
+        for (int m : s.mesh.material_ids) {
+            if (mat_ids) mat_ids[t] = m;
+            ++t;
+        }
+        if (shape_tris) shape_tris[si] = (int)(s.mesh.indices.size() / 3);
+        ++si;
+    }
+}
+
+PTH_API void pth_obj_shape_name(const PthObj* o, int i, char* name, int cap) { copy_text(name, cap, o->shapes[i].name); }
+
+// values19: Ka Kd Ks Kt Ke (3 each), Ns, Ni, d, illum
+PTH_API void pth_obj_material(const PthObj* o, int i, char* name, int cap, float* values19) {
+    const ptobj::material_t& m = o->materials[i];
+    copy_text(name, cap, m.name);
+    const float* groups[5] = {m.ambient, m.diffuse, m.specular, m.transmittance, m.emission};
+    for (int g = 0; g < 5; ++g)
+        for (int c = 0; c < 3; ++c) values19[3 * g + c] = groups[g][c];
+    values19[15] = m.shininess;
+    values19[16] = m.ior;
+    values19[17] = m.dissolve;
+    values19[18] = (float)m.illum;
+}
+
+// Mesh as main() builds it: vertices6 = positions x {pos, normal}, indices = triangles x 3, material_ids per triangle.
+// Returns 1 when the OBJ carries a normal for every position (vertex-normal mode usable), else 0.
+PTH_API int pth_obj_build_mesh(const PthObj* o, float scale, float translate_z, float* vertices6, unsigned* indices, int* material_ids) {
+    pthost::Mesh m = pthost::buildMesh(o->attrib, o->shapes, scale, pthost::float3(0.f, 0.f, translate_z));
+    if (vertices6 && !m.vertices.empty()) memcpy(vertices6, m.vertices.data(), m.vertices.size() * sizeof(pthost::Vertex));
+    if (indices)
+        for (size_t i = 0; i < m.indices.size(); ++i) indices[i] = (unsigned)m.indices[i];
+    if (material_ids && !m.material_ids.empty()) memcpy(material_ids, m.material_ids.data(), m.material_ids.size() * sizeof(int));
+    return m.has_vertex_normals ? 1 : 0;
+}
+
+// out12 = position, lowerLeftCorner, horizontal, vertical
+PTH_API void pth_camera(float fov, float width, float height, const float* eye, const float* target, const float* up, float* out12) {
+    pthost::Camera c;
+    c.initialize(fov, 0.1f, 100.f, width, height);
+    c.lookAt(pthost::float3(eye[0], eye[1], eye[2]), pthost::float3(target[0], target[1], target[2]),
+             pthost::float3(up[0], up[1], up[2]));
+    const pthost::float3* v[4] = {&c.position, &c.lowerLeftCorner, &c.horizontal, &c.vertical};
+    for (int k = 0; k < 4; ++k) { out12[3 * k] = v[k]->x; out12[3 * k + 1] = v[k]->y; out12[3 * k + 2] = v[k]->z; }
+}
+
+PTH_API void pth_reference_spheres(float* spheres40, float* materials40) {
+    pthost::Scene s;
+    pthost::buildReferenceSpheres(s);
+    memcpy(spheres40, s.spheres.data(), 160);
+    memcpy(materials40, s.materials.data(), 160);
+}
+
+PTH_API float pth_parse_float(const char* text, double fallback) { return ptobj::ParseFloatText(text, text + strlen(text), fallback); }
+
+// 0 none, 1 world, 2 mesh, 3 present
+PTH_API int pth_shader_classify_text(const char* code) { return (int)Shader::ClassifySource(code); }
+
+// Loads a fragment shader by file name through the Shader class and reports the stage it selected.
+PTH_API int pth_shader_stage_for_file(const char* filename) {
+    Shader s;
+    s.loadFragmentShader(filename);
+    return (int)s.getStage();
+}
+
+// The whole render loop. rgb_sum (may be NULL) receives Framebuffer::accumulationBuffer (w*h*3), rgba8 (may be NULL)
+// Framebuffer::colorBuffer (w*h*4). stats3 = rays, samples, device milliseconds. Returns 0 on success.
+PTH_API int pth_render(const char* obj_path, const char* mtl_basedir, int width, int height, int passes, int samples_per_dispatch,
+                       int program_kind, int device, const char* output_tga, float* rgb_sum, unsigned char* rgba8, double* stats3,
+                       char* err, int err_cap) {
+    pthost::RenderOptions opt;
+    opt.obj_path = obj_path;
+    opt.mtl_basedir = mtl_basedir ? mtl_basedir : "";
+    opt.width = width;
+    opt.height = height;
+    opt.passes = passes;
+    opt.samples_per_dispatch = samples_per_dispatch;
+    opt.program_kind = program_kind;
+    opt.device = device;
+    opt.quiet = true;
+    opt.output_tga = output_tga ? output_tga : "";
+    Framebuffer fb;
+    pthost::RenderResult res;
+    const int rc = pthost::RunRenderLoop(opt, fb, res);
+    if (rc == 0) {
+        const size_t n = (size_t)width * height;
+        if (rgb_sum) memcpy(rgb_sum, fb.accumulationBuffer, n * 3 * sizeof(float));
+        if (rgba8) memcpy(rgba8, fb.colorBuffer, n * 4);
+        if (stats3) { stats3[0] = (double)res.rays; stats3[1] = (double)res.samples; stats3[2] = res.device_ms; }
+    }
+    copy_text(err, err_cap, res.error);
+    fb.destroy();
+    return rc;
+}

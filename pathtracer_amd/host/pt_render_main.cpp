@@ -1,0 +1,42 @@
+// Command-line front end of the render loop: the headless counterpart of the reference executable.
+//   pt_render [--obj file.obj] [--mtl-dir dir/] [--size WxH] [--passes N] [--batch N] [--kind world|mesh]
+//             [--device N] [--out image.tga] [--quiet]
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "RenderLoop.h"
+
+int main(int argc, char** argv) {
+    pthost::RenderOptions opt;
+    for (int i = 1; i < argc; ++i) {
+        auto next = [&](const char* flag) -> const char* {
+            if (i + 1 >= argc) { fprintf(stderr, "%s needs a value\n", flag); exit(2); }
+            return argv[++i];
+        };
+        if (!strcmp(argv[i], "--obj")) opt.obj_path = next("--obj");
+        else if (!strcmp(argv[i], "--mtl-dir")) opt.mtl_basedir = next("--mtl-dir");
+        else if (!strcmp(argv[i], "--shader-dir")) opt.shader_dir = next("--shader-dir");
+        else if (!strcmp(argv[i], "--size")) { if (sscanf(next("--size"), "%dx%d", &opt.width, &opt.height) != 2) { fprintf(stderr, "--size WxH\n"); return 2; } }
+        else if (!strcmp(argv[i], "--passes")) opt.passes = atoi(next("--passes"));
+        else if (!strcmp(argv[i], "--batch")) opt.samples_per_dispatch = atoi(next("--batch"));
+        else if (!strcmp(argv[i], "--depth")) opt.depth = atoi(next("--depth"));
+        else if (!strcmp(argv[i], "--device")) opt.device = atoi(next("--device"));
+        else if (!strcmp(argv[i], "--kind")) { const char* k = next("--kind"); opt.program_kind = !strcmp(k, "mesh") ? 1 : 0; }
+        else if (!strcmp(argv[i], "--out")) opt.output_tga = next("--out");
+        else if (!strcmp(argv[i], "--quiet")) opt.quiet = true;
+        else { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
+    }
+    Framebuffer fb;
+    pthost::RenderResult res;
+    const int rc = pthost::RunRenderLoop(opt, fb, res);
+    if (rc != 0) {
+        fprintf(stderr, "pt_render: %s\n", res.error.c_str());
+    } else {
+        printf("%d triangles, %llu samples, %llu rays, %.3f s wall, %.3f ms on device, %.1f Mrays/s\n", res.triangles,
+               (unsigned long long)res.samples, (unsigned long long)res.rays, res.seconds, res.device_ms,
+               res.rays / res.seconds * 1e-6);
+    }
+    fb.destroy();
+    return rc;
+}

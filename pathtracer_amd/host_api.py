@@ -1,0 +1,132 @@
+"""ctypes binding of the C++ host library (pathtracer_amd/lib/libpt_host.so): OBJ/MTL loading, the reference's
+scene construction and camera, the Shader stage classifier and the render loop."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpt_host.so")
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python -m pathtracer_amd.build`")
+        L = C.CDLL(LIB_PATH)
+        L.pth_obj_load.restype = C.c_void_p
+        L.pth_obj_load.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
+        L.pth_obj_free.argtypes = [C.c_void_p]
+        L.pth_obj_counts.argtypes = [C.c_void_p, C.c_void_p]
+        L.pth_obj_copy.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+        L.pth_obj_shape_name.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int]
+        L.pth_obj_material.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_void_p]
+        L.pth_obj_build_mesh.restype = C.c_int
+        L.pth_obj_build_mesh.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.pth_camera.argtypes = [C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.pth_reference_spheres.argtypes = [C.c_void_p, C.c_void_p]
+        L.pth_parse_float.restype = C.c_float
+        L.pth_parse_float.argtypes = [C.c_char_p, C.c_double]
+        L.pth_shader_classify_text.restype = C.c_int
+        L.pth_shader_classify_text.argtypes = [C.c_char_p]
+        L.pth_shader_stage_for_file.restype = C.c_int
+        L.pth_shader_stage_for_file.argtypes = [C.c_char_p]
+        L.pth_render.restype = C.c_int
+        L.pth_render.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
+        _lib = L
+    return _lib
+
+
+class ObjFile:
+    """What the host's OBJ/MTL reader returns for one file (arrays copied out of the C++ objects)."""
+
+    def __init__(self, path, mtl_basedir=None):
+        L = load()
+        err = C.create_string_buffer(2048)
+        h = L.pth_obj_load(path.encode(), mtl_basedir.encode() if mtl_basedir is not None else None, err, len(err))
+        self.err = err.value.decode(errors="replace")
+        if not h:
+            raise FileNotFoundError(self.err or path)
+        try:
+            cnt = (C.c_int * 5)()
+            L.pth_obj_counts(h, cnt)
+            nv, nvn, nt, ns, nm = list(cnt)
+            self.v = np.zeros((nv, 3), np.float32)
+            self.vn = np.zeros((nvn, 3), np.float32)
+            self.idx_v = np.zeros((nt, 3), np.int32)
+            self.idx_vn = np.zeros((nt, 3), np.int32)
+            self.mat_ids = np.zeros(nt, np.int32)
+            self.shape_tris = np.zeros(ns, np.int32)
+            L.pth_obj_copy(h, self.v.ctypes.data, self.vn.ctypes.data, self.idx_v.ctypes.data, self.idx_vn.ctypes.data,
+                           self.mat_ids.ctypes.data, self.shape_tris.ctypes.data)
+            name = C.create_string_buffer(256)
+            self.shape_names = []
+            for i in range(ns):
+                L.pth_obj_shape_name(h, i, name, len(name))
+                self.shape_names.append(name.value.decode())
+            self.mat_names, vals = [], np.zeros((nm, 19), np.float32)
+            for i in range(nm):
+                L.pth_obj_material(h, i, name, len(name), vals[i].ctypes.data)
+                self.mat_names.append(name.value.decode())
+            self.mat_values = vals
+            # the mesh as main() builds it
+            self._mesh_cache = {}
+            self._handle_counts = (nv, nt)
+            self._build = lambda scale, tz: self._build_mesh(L, h, scale, tz)
+            self.mesh_default = self._build_mesh(L, h, 1.0, 3.0)
+            self.mesh_untranslated = self._build_mesh(L, h, 1.0, 0.0)
+        finally:
+            L.pth_obj_free(h)
+
+    def _build_mesh(self, L, h, scale, tz):
+        nv, nt = self._handle_counts
+        verts = np.zeros((nv, 6), np.float32)
+        idx = np.zeros((nt, 3), np.uint32)
+        mids = np.zeros(nt, np.int32)
+        has_n = L.pth_obj_build_mesh(h, scale, tz, verts.ctypes.data, idx.ctypes.data, mids.ctypes.data)
+        return {"vertices": verts, "indices": idx, "material_ids": mids, "has_vertex_normals": bool(has_n)}
+
+
+def camera(fov_deg, width, height, eye, target, up):
+    out = np.zeros(12, np.float32)
+    e, t, u = (np.asarray(v, np.float32) for v in (eye, target, up))
+    load().pth_camera(fov_deg, float(width), float(height), e.ctypes.data, t.ctypes.data, u.ctypes.data, out.ctypes.data)
+    return out
+
+
+def reference_spheres():
+    s, m = np.zeros((10, 4), np.float32), np.zeros((10, 4), np.float32)
+    load().pth_reference_spheres(s.ctypes.data, m.ctypes.data)
+    return s, m
+
+
+def parse_float(text, fallback=0.0):
+    return np.float32(load().pth_parse_float(text.encode(), fallback))
+
+
+STAGES = {0: "none", 1: "world", 2: "mesh", 3: "present"}
+
+
+def shader_classify_text(code):
+    return STAGES[load().pth_shader_classify_text(code.encode())]
+
+
+def shader_stage_for_file(filename):
+    return STAGES[load().pth_shader_stage_for_file(filename.encode())]
+
+
+def render(obj_path, width, height, passes, samples_per_dispatch=1, program_kind=1, device=0, mtl_basedir=None, output_tga=None):
+    """Runs the C++ render loop; returns (accumulationBuffer [h,w,3] running sum, colorBuffer [h,w,4] uint8, stats)."""
+    rgb = np.zeros((height, width, 3), np.float32)
+    rgba8 = np.zeros((height, width, 4), np.uint8)
+    stats = np.zeros(3, np.float64)
+    err = C.create_string_buffer(1024)
+    rc = load().pth_render(obj_path.encode(), mtl_basedir.encode() if mtl_basedir else None, width, height, passes,
+                           samples_per_dispatch, program_kind, device, output_tga.encode() if output_tga else None,
+                           rgb.ctypes.data, rgba8.ctypes.data, stats.ctypes.data, err, len(err))
+    if rc != 0:
+        raise RuntimeError(err.value.decode(errors="replace"))
+    return rgb, rgba8, {"rays": int(stats[0]), "samples": int(stats[1]), "device_ms": float(stats[2])}
