@@ -77,6 +77,8 @@ typedef struct PtStats {
     uint64_t rays;             /* closest-hit queries since the last pt_reset_stats(): one per bounce-loop iteration
                                   (the reference's definition, PathTracer.cpp:947; its GLSL mode never counts, :1315) */
     uint64_t samples;          /* pixel-samples (shader invocations) */
+    uint64_t lane_slots;       /* 64 x the loop trips of every wave: rays / lane_slots is the fraction of SIMD lanes
+                                  that did useful work (paths in one wave end at different times) */
     uint32_t dispatches;       /* render-kernel launches */
     float last_dispatch_ms;    /* duration of the most recent render kernel; 0 unless timing is enabled */
     double total_dispatch_ms;  /* sum over dispatches since the last reset; 0 unless timing is enabled */

@@ -5,6 +5,8 @@
                                      camera, OBJ/MTL loading, render loop) on top of the C ABI
 
 The device flags are part of the numerics contract: no fp contraction, denormals flushed, IEEE divide/sqrt.
+-fno-slp-vectorize is a speed flag: packed fp32 (v_pk_mul_f32/v_pk_add_f32) runs at half the instruction rate on
+gfx950, so pairing scalar operations into packed ones only adds register shuffles (measured: 1.3x slower with them).
 """
 import os
 import shutil
@@ -19,7 +21,7 @@ LIB = os.path.join(HERE, "lib")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 DEVICE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-                "-fgpu-flush-denormals-to-zero", "-fno-fast-math", "-fvisibility=hidden", "-Wall", "-Wextra",
+                "-fgpu-flush-denormals-to-zero", "-fno-fast-math", "-fno-slp-vectorize", "-fvisibility=hidden", "-Wall", "-Wextra",
                 "-Wno-unused-parameter"]
 
 
@@ -38,16 +40,17 @@ def _run(cmd):
     return r
 
 
-def build_hip(force=False, save_temps=False):
+def build_hip(force=False, save_temps=False, extra_flags=(), tag=""):
+    """tag/extra_flags build an experimental variant next to the product library (tools/ab_bench.py)."""
     os.makedirs(LIB, exist_ok=True)
-    out = os.path.join(LIB, "libpt_hip.so")
+    out = os.path.join(LIB, f"libpt_hip{('__' + tag) if tag else ''}.so")
     srcs = [os.path.join(CSRC, f) for f in ("pt_kernels.hip", "pt_capi.hip")]
     deps = srcs + [os.path.join(CSRC, "pt_internal.h"), os.path.join(ROOT, "include", "pt_hip.h"), __file__]
     if not force and not _newer(out, deps):
         return out
     if shutil.which(HIPCC) is None:
         raise RuntimeError(f"{HIPCC} not found: the HIP library cannot be built")
-    cmd = [HIPCC] + DEVICE_FLAGS + ["-shared", "-o", out] + srcs
+    cmd = [HIPCC] + DEVICE_FLAGS + list(extra_flags) + ["-shared", "-o", out] + srcs
     if save_temps:
         tmp = os.path.join(LIB, "temps")
         os.makedirs(tmp, exist_ok=True)

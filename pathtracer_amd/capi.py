@@ -25,7 +25,7 @@ class PtUniforms(C.Structure):
 
 
 class PtStats(C.Structure):
-    _fields_ = [("rays", C.c_uint64), ("samples", C.c_uint64), ("dispatches", C.c_uint32),
+    _fields_ = [("rays", C.c_uint64), ("samples", C.c_uint64), ("lane_slots", C.c_uint64), ("dispatches", C.c_uint32),
                 ("last_dispatch_ms", C.c_float), ("total_dispatch_ms", C.c_double)]
 
 
@@ -66,27 +66,28 @@ SIGNATURES = {
     "pt_reset_stats": (C.c_int, [C.c_void_p]),
 }
 
-_lib = None
+_libs = {}
 
 
-def load():
-    """Loads libpt_hip.so and binds every entry point. Raises if the library has not been built."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError(f"{LIB_PATH} is missing: run `python -m pathtracer_amd.build` (needs hipcc). "
+def load(path=None):
+    """Loads libpt_hip.so (or an experimental build at `path`) and binds every entry point. Raises if the library
+    has not been built."""
+    path = path or LIB_PATH
+    if path not in _libs:
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run `python -m pathtracer_amd.build` (needs hipcc). "
                                "There is no CPU fallback.")
-        lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
-        _lib = lib
-    return _lib
+        _libs[path] = lib
+    return _libs[path]
 
 
-def check(status):
+def check(status, lib=None):
     if status != PT_OK:
-        raise PtError(status, load().pt_last_error().decode("utf-8", "replace"))
+        raise PtError(status, (lib or load()).pt_last_error().decode("utf-8", "replace"))
 
 
 def device_count():
@@ -98,10 +99,10 @@ def device_count():
 class Tracer:
     """One context (device + stream) with the calls of include/pt_hip.h as methods. Thin: argument packing only."""
 
-    def __init__(self, device=0):
-        self._lib = load()
+    def __init__(self, device=0, lib_path=None):
+        self._lib = load(lib_path)
         self._ctx = C.c_void_p()
-        check(self._lib.pt_create(device, C.byref(self._ctx)))
+        check(self._lib.pt_create(device, C.byref(self._ctx)), self._lib)
         self.width = self.height = 0
 
     def close(self):
@@ -124,52 +125,52 @@ class Tracer:
     # -- program
     def program_create(self, kind):
         h = C.c_uint32(0)
-        check(self._lib.pt_program_create(self._ctx, kind, C.byref(h)))
+        check(self._lib.pt_program_create(self._ctx, kind, C.byref(h)), self._lib)
         return h.value
 
     def program_destroy(self, program):
-        check(self._lib.pt_program_destroy(self._ctx, program))
+        check(self._lib.pt_program_destroy(self._ctx, program), self._lib)
 
     def use_program(self, program):
-        check(self._lib.pt_use_program(self._ctx, program))
+        check(self._lib.pt_use_program(self._ctx, program), self._lib)
 
     def set_stream(self, hip_stream):
-        check(self._lib.pt_set_stream(self._ctx, C.c_void_p(hip_stream)))
+        check(self._lib.pt_set_stream(self._ctx, C.c_void_p(hip_stream)), self._lib)
 
     # -- scene
     def upload_spheres(self, xyzr):
         a = np.ascontiguousarray(xyzr, np.float32).reshape(-1, 4)
-        check(self._lib.pt_upload_spheres(self._ctx, a.ctypes.data, len(a)))
+        check(self._lib.pt_upload_spheres(self._ctx, a.ctypes.data, len(a)), self._lib)
 
     def upload_materials(self, rgbt):
         a = np.ascontiguousarray(rgbt, np.float32).reshape(-1, 4)
-        check(self._lib.pt_upload_materials(self._ctx, a.ctypes.data, len(a)))
+        check(self._lib.pt_upload_materials(self._ctx, a.ctypes.data, len(a)), self._lib)
 
     def upload_mesh(self, vertices, indices):
         v = np.ascontiguousarray(vertices, np.float32).reshape(-1, 6)
         i = np.ascontiguousarray(indices, np.uint32).reshape(-1, 3)
-        check(self._lib.pt_upload_mesh(self._ctx, v.ctypes.data, len(v), i.ctypes.data, len(i)))
+        check(self._lib.pt_upload_mesh(self._ctx, v.ctypes.data, len(v), i.ctypes.data, len(i)), self._lib)
 
     def set_normal_mode(self, mode):
-        check(self._lib.pt_set_normal_mode(self._ctx, mode))
+        check(self._lib.pt_set_normal_mode(self._ctx, mode), self._lib)
 
     # -- target
     def target_create(self, width, height):
-        check(self._lib.pt_target_create(self._ctx, width, height))
+        check(self._lib.pt_target_create(self._ctx, width, height), self._lib)
         self.width, self.height = width, height
 
     def target_bind_external(self, ptr_a, ptr_b, width, height):
-        check(self._lib.pt_target_bind_external(self._ctx, C.c_void_p(ptr_a), C.c_void_p(ptr_b), width, height))
+        check(self._lib.pt_target_bind_external(self._ctx, C.c_void_p(ptr_a), C.c_void_p(ptr_b), width, height), self._lib)
         self.width, self.height = width, height
 
     def target_clear(self):
-        check(self._lib.pt_target_clear(self._ctx))
+        check(self._lib.pt_target_clear(self._ctx), self._lib)
 
     def set_window(self, x0=0, y0=0, w=0, h=0):
-        check(self._lib.pt_set_window(self._ctx, x0, y0, w, h))
+        check(self._lib.pt_set_window(self._ctx, x0, y0, w, h), self._lib)
 
     def set_accum_mode(self, mode):
-        check(self._lib.pt_set_accum_mode(self._ctx, mode))
+        check(self._lib.pt_set_accum_mode(self._ctx, mode), self._lib)
 
     # -- per frame
     def set_uniforms(self, camera12, num_triangles, depth=10):
@@ -181,39 +182,39 @@ class Tracer:
             u.camera_horizontal[k] = cam[6 + k]
             u.camera_vertical[k] = cam[9 + k]
         u.num_triangles, u.depth = int(num_triangles), int(depth)
-        check(self._lib.pt_set_uniforms(self._ctx, C.byref(u)))
+        check(self._lib.pt_set_uniforms(self._ctx, C.byref(u)), self._lib)
 
     def dispatch(self, first_sample, num_samples=1, stride=1):
-        check(self._lib.pt_dispatch(self._ctx, first_sample, num_samples, stride))
+        check(self._lib.pt_dispatch(self._ctx, first_sample, num_samples, stride), self._lib)
 
     def finish(self):
-        check(self._lib.pt_finish(self._ctx))
+        check(self._lib.pt_finish(self._ctx), self._lib)
 
     # -- results
     def readback(self):
         out = np.empty((self.height, self.width, 4), np.float32)
-        check(self._lib.pt_readback_rgba32f(self._ctx, out.ctypes.data))
+        check(self._lib.pt_readback_rgba32f(self._ctx, out.ctypes.data), self._lib)
         return out
 
     def current_image_ptr(self):
         p = C.c_void_p()
-        check(self._lib.pt_current_image(self._ctx, C.byref(p)))
+        check(self._lib.pt_current_image(self._ctx, C.byref(p)), self._lib)
         return p.value
 
     def readback_primary(self):
         ids = np.empty((self.height, self.width), np.int32)
         t = np.empty((self.height, self.width), np.float32)
-        check(self._lib.pt_readback_primary(self._ctx, ids.ctypes.data, t.ctypes.data))
+        check(self._lib.pt_readback_primary(self._ctx, ids.ctypes.data, t.ctypes.data), self._lib)
         return ids, t
 
     def enable_timing(self, on=True):
-        check(self._lib.pt_enable_timing(self._ctx, 1 if on else 0))
+        check(self._lib.pt_enable_timing(self._ctx, 1 if on else 0), self._lib)
 
     def stats(self):
         s = PtStats()
-        check(self._lib.pt_get_stats(self._ctx, C.byref(s)))
-        return {"rays": s.rays, "samples": s.samples, "dispatches": s.dispatches,
+        check(self._lib.pt_get_stats(self._ctx, C.byref(s)), self._lib)
+        return {"rays": s.rays, "samples": s.samples, "lane_slots": s.lane_slots, "dispatches": s.dispatches,
                 "last_dispatch_ms": s.last_dispatch_ms, "total_dispatch_ms": s.total_dispatch_ms}
 
     def reset_stats(self):
-        check(self._lib.pt_reset_stats(self._ctx))
+        check(self._lib.pt_reset_stats(self._ctx), self._lib)

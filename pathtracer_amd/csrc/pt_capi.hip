@@ -339,7 +339,8 @@ PtStatus pt_upload_mesh(PtContext* ctx, const float* vertices, int32_t num_verti
     const size_t nt = (size_t)num_triangles;
     PT_HIP_TRY(hipMalloc(&ctx->d_vertices, (size_t)num_vertices * 6 * sizeof(float)));
     PT_HIP_TRY(hipMalloc(&ctx->d_indices, nt * 3 * sizeof(uint32_t)));
-    PT_HIP_TRY(hipMalloc(&ctx->d_tris, nt * PT_TRI_FLOATS * sizeof(float)));
+    PT_HIP_TRY(hipMalloc(&ctx->d_tris, (nt + PT_TRI_PAD) * PT_TRI_FLOATS * sizeof(float)));
+    PT_HIP_TRY(hipMemsetAsync(ctx->d_tris + nt * PT_TRI_FLOATS, 0, PT_TRI_PAD * PT_TRI_FLOATS * sizeof(float), ctx->stream));
     PT_HIP_TRY(hipMalloc(&ctx->d_vnormals, nt * 9 * sizeof(float)));
     PT_HIP_TRY(hipMalloc(&ctx->d_gnormals, nt * 3 * sizeof(float)));
     PT_HIP_TRY(hipMemcpyAsync(ctx->d_vertices, vertices, (size_t)num_vertices * 6 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
@@ -544,6 +545,7 @@ PtStatus pt_get_stats(PtContext* ctx, PtStats* out) {
     PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
     out->rays = c[0];
     out->samples = ctx->samples;
+    out->lane_slots = c[1];
     out->dispatches = ctx->dispatches;
     out->last_dispatch_ms = ctx->last_ms;
     out->total_dispatch_ms = ctx->total_ms;

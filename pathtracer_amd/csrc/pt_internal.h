@@ -14,6 +14,9 @@
 //   e2r = dot(e2, r)                      (numerator of pathtracing.fs:160)
 // The values are produced by the same fp32 operations in the same order, so results are bit-identical.
 #define PT_TRI_FLOATS 16
+// All-zero records appended to the triangle buffer: the triangle loop runs in steps of 4 and requests records up to
+// 5 past the last real one.
+#define PT_TRI_PAD 8
 struct PtTriRecordLayout {
     enum { E1 = 0, E2 = 3, AP = 6, R = 9, E2R = 12 };
 };
@@ -32,7 +35,7 @@ struct PtKernelParams {
     const float* spheres;               // 10 x (cx, cy, cz, r)
     const float* src;                   // RGBA32F image read (previous result)
     float* dst;                         // RGBA32F image written
-    unsigned long long* counters;       // [0] rays, [1] samples
+    unsigned long long* counters;       // [0] rays, [1] lane slots spent (wave loop trips x 64)
     int32_t* out_ids;                   // primary pass only
     float* out_t;                       // primary pass only
 };

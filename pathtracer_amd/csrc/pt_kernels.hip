@@ -117,31 +117,62 @@ struct Hit {
     float u, v, ood;  // mesh only: the two barycentric numerators and 1/det of the accepted triangle
 };
 
-// fs:125-174 with the direction-independent parts taken from the triangle record (see pt_internal.h).
-// The record address is wave-uniform, so the compiler fetches it with scalar loads.
+// One ray against one triangle record: fs:139-168 with the direction-independent parts taken from the record
+// (see pt_internal.h). The record registers are wave-uniform (scalar).
+struct TriRec { float4 a, b, c, d; };  // e1.xyz e2.x | e2.yz ap.xy | ap.z r.xyz | e2r - - -
+
+__device__ __forceinline__ void test_triangle(const TriRec& t, int id, v3 rd, Hit& h) {
+    const v3 e1 = V(t.a.x, t.a.y, t.a.z);
+    const v3 e2 = V(t.a.w, t.b.x, t.b.y);
+    const v3 q = cross3(rd, e2);
+    const float det = dot3(e1, q);
+#ifndef PT_V_NO_DETSKIP
+    // wave-uniform skip: when no lane sees the front of the triangle the two remaining dot products are not needed
+    if (!__builtin_amdgcn_ballot_w64(det >= 0.0001f)) return;
+#endif
+    const v3 ap = V(t.b.z, t.b.w, t.c.x);
+    const v3 r = V(t.c.y, t.c.z, t.c.w);
+    const float u = dot3(ap, q);
+    const float v = dot3(rd, r);
+    // fs:142,151. "u <= det" is implied by the other three (v >= 0 makes fl(u+v) >= u), so it is not evaluated.
+    const bool inside = (det >= 0.0001f) & (u >= 0.0f) & (v >= 0.0f) & ((u + v) <= det);
+    if (inside) {
+        const float ood = 1.0f / det;
+        const float tt = t.d.x * ood;
+        if (tt > 0.0f && tt < h.t) {  // strict '<' in ascending id: the lowest index wins ties
+            h.t = tt; h.id = id; h.u = u; h.v = v; h.ood = ood;
+        }
+    }
+}
+
+__device__ __forceinline__ TriRec load_rec(const float4* __restrict__ recs, int i) {
+    TriRec t;
+    t.a = recs[4 * i]; t.b = recs[4 * i + 1]; t.c = recs[4 * i + 2]; t.d = recs[4 * i + 3];
+    return t;
+}
+
+// fs:125-174: closest hit over triangles 0..n-1 in ascending order. The record address is the same in every lane,
+// so records arrive through scalar loads; they are requested two triangles ahead of their use (two register sets,
+// alternating), which keeps the scalar-load latency off the wave's critical path. The buffer is padded with
+// PT_TRI_PAD all-zero records (det = 0 fails the cull), so the loop needs no remainder handling.
 __device__ __forceinline__ Hit intersect_mesh(const float* __restrict__ tris, int n, v3 rd) {
     Hit h;
     h.t = 1.0e38f; h.id = -1; h.u = 0.f; h.v = 0.f; h.ood = 0.f;
-    for (int i = 0; i < n; ++i) {
-        const float* __restrict__ rec = tris + (size_t)i * PT_TRI_FLOATS;
-        const v3 e1 = V(rec[0], rec[1], rec[2]);
-        const v3 e2 = V(rec[3], rec[4], rec[5]);
-        const v3 ap = V(rec[6], rec[7], rec[8]);
-        const v3 r = V(rec[9], rec[10], rec[11]);
-        const float e2r = rec[12];
-        const v3 q = cross3(rd, e2);
-        const float det = dot3(e1, q);
-        const float u = dot3(ap, q);
-        const float v = dot3(rd, r);
-        const bool inside = (det >= 0.0001f) & (u >= 0.0f) & (u <= det) & (v >= 0.0f) & ((u + v) <= det);
-        if (inside) {
-            const float ood = 1.0f / det;
-            const float t = e2r * ood;
-            if (t > 0.0f && t < h.t) {  // strict '<' in ascending i: the lowest index wins ties
-                h.t = t; h.id = i; h.u = u; h.v = v; h.ood = ood;
-            }
-        }
+    const float4* __restrict__ recs = reinterpret_cast<const float4*>(tris);
+#ifdef PT_V_SIMPLE
+    for (int i = 0; i < n; ++i) test_triangle(load_rec(recs, i), i, rd, h);
+#else
+    TriRec a0 = load_rec(recs, 0), a1 = load_rec(recs, 1);
+    for (int i = 0; i < n; i += 4) {
+        const TriRec b0 = load_rec(recs, i + 2), b1 = load_rec(recs, i + 3);
+        test_triangle(a0, i, rd, h);
+        test_triangle(a1, i + 1, rd, h);
+        a0 = load_rec(recs, i + 4);
+        a1 = load_rec(recs, i + 5);
+        test_triangle(b0, i + 2, rd, h);
+        test_triangle(b1, i + 3, rd, h);
     }
+#endif
     return h;
 }
 
@@ -235,6 +266,15 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
     return v;
 }
 
+__device__ __forceinline__ unsigned __reduce_max_trips(unsigned v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
 template <int KIND>  // PtProgramKind
 __global__ __launch_bounds__(256) void pt_render_kernel(const PtKernelParams p) {
     int x, y;
@@ -254,6 +294,7 @@ __global__ __launch_bounds__(256) void pt_render_kernel(const PtKernelParams p) 
     int remaining = in_window ? p.num_samples : 0;
     int sample = p.first_sample;
     unsigned rays = 0;
+    unsigned trips = 0;  // loop trips of this wave: trips x 64 lane slots were spent for `rays` useful ones
 
     // path state
     v3 rd = rd0;
@@ -268,6 +309,7 @@ __global__ __launch_bounds__(256) void pt_render_kernel(const PtKernelParams p) 
         if (KIND == 0) h = intersect_world(p.spheres, ro, rd, N);
         else h = intersect_mesh(p.tris, p.num_triangles, rd);
         ++rays;
+        ++trips;
         const bool hit = h.id >= 0;
         if (hit) {
             if (KIND != 0) N = mesh_normal(p, h);
@@ -300,7 +342,11 @@ __global__ __launch_bounds__(256) void pt_render_kernel(const PtKernelParams p) 
         reinterpret_cast<float4*>(p.dst)[pix] = make_float4(mr, mg, mb, alpha);
     }
     const unsigned long long wave_rays = wave_sum(rays);
-    if ((threadIdx.x & 63) == 0 && wave_rays) atomicAdd(&p.counters[0], wave_rays);
+    const unsigned wave_trips = __builtin_amdgcn_readfirstlane(__reduce_max_trips(trips));
+    if ((threadIdx.x & 63) == 0 && wave_rays) {
+        atomicAdd(&p.counters[0], wave_rays);
+        atomicAdd(&p.counters[1], (unsigned long long)wave_trips * 64ull);
+    }
 }
 
 template <int KIND>

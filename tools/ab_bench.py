@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""A/B timing of experimental builds of the HIP library in ONE process, rounds interleaved (kernel variants are
+compared on the same device, same clocks, same data). Build the variants first on the CPU box:
+
+    python tools/ab_bench.py --build            # compiles pathtracer_amd/lib/libpt_hip__<tag>.so for every variant
+    python tools/ab_bench.py --workload cornell --spp 64 --rounds 5     # on the GPU box
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+VARIANTS = {
+    "product": [],
+    "simple": ["-DPT_V_SIMPLE"],
+    "no_detskip": ["-DPT_V_NO_DETSKIP"],
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--build", action="store_true")
+    ap.add_argument("--workload", default="cornell")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--spp", type=int, default=64)
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    from pathtracer_amd import build as ptbuild
+    names = [v for v in VARIANTS if not args.only or v in args.only.split(",")]
+    if args.build:
+        for v in names:
+            print(ptbuild.build_hip(force=True, extra_flags=VARIANTS[v], tag=v))
+        return
+    import numpy as np
+    from pathtracer_amd import Tracer
+    from pathtracer_amd.scenes import SceneData
+    scene = SceneData(args.workload, args.width, args.height)
+    tracers, ref = {}, None
+    for v in names:
+        t = Tracer(0, os.path.join(ROOT, "pathtracer_amd", "lib", f"libpt_hip__{v}.so"))
+        scene.upload(t)
+        t.target_create(scene.width, scene.height)
+        t.enable_timing(True)
+        t.dispatch(1, 2, 1)
+        t.finish()
+        img = t.readback()
+        if ref is None:
+            ref = img
+        same = bool(np.array_equal(img.view(np.uint32), ref.view(np.uint32)))
+        tracers[v] = (t, same)
+    times = {v: [] for v in names}
+    util = {}
+    for _ in range(args.rounds):
+        for v in names:
+            t, _ = tracers[v]
+            t.target_clear()
+            t.reset_stats()
+            t.dispatch(1, args.spp, 1)
+            t.finish()
+            st = t.stats()
+            times[v].append(st["last_dispatch_ms"])
+            util[v] = (st["rays"], st["rays"] / max(1, st["lane_slots"]))
+    for v in names:
+        rays, u = util[v]
+        ms = statistics.median(times[v])
+        print(json.dumps({"variant": v, "median_ms": round(ms, 3), "min_ms": round(min(times[v]), 3),
+                          "Grays_per_s": round(rays / ms * 1e-6, 2), "lane_utilisation": round(u, 4),
+                          "same_image_as_first": tracers[v][1]}))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""One warm-up and N timed dispatches of a workload: the program to put behind rocprofv3."""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="cornell")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--spp", type=int, default=64)
+    ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--lib", default=None)
+    args = ap.parse_args()
+    from pathtracer_amd import Tracer
+    from pathtracer_amd.scenes import SceneData
+    scene = SceneData(args.workload, args.width, args.height)
+    t = Tracer(0, args.lib)
+    scene.upload(t)
+    t.target_create(scene.width, scene.height)
+    t.enable_timing(True)
+    t.dispatch(1, 1, 1)
+    t.finish()
+    t.reset_stats()
+    for _ in range(args.reps):
+        t.target_clear()
+        t.dispatch(1, args.spp, 1)
+        t.finish()
+    st = t.stats()
+    ms = st["total_dispatch_ms"] / st["dispatches"]
+    print(json.dumps({"workload": args.workload, "size": [scene.width, scene.height], "spp": args.spp, "triangles": scene.num_triangles,
+                      "kernel_ms": ms, "Grays_per_s": st["rays"] / st["dispatches"] / ms * 1e-6,
+                      "rays_per_sample": st["rays"] / st["samples"], "lane_utilisation": st["rays"] / st["lane_slots"]}))
+    t.close()
+
+
+if __name__ == "__main__":
+    main()
