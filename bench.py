@@ -57,6 +57,12 @@ def cpu_baseline(scene, spp_hint, budget_s=12.0):
                       f"{rays} rays in {dt:.2f} s (oracle/pt_oracle.c, {threads} threads)"}
 
 
+def trace(msg):
+    """Progress lines on stderr when PT_BENCH_TRACE=1 (finding where a multi-process run stops)."""
+    if os.environ.get("PT_BENCH_TRACE") == "1":
+        print(f"[bench rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -81,12 +87,21 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+    # Rehearsal knobs for a one-GPU box (never set by the driver): PT_BENCH_SHARE_GPU=1 puts every rank on device 0 and
+    # PT_BENCH_BACKEND=gloo replaces RCCL, which refuses two ranks on one device.
+    if os.environ.get("PT_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
+    backend = os.environ.get("PT_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
+    trace("process group up")
     scene = SceneData(args.workload, args.width, args.height)
     W, H, spp = scene.width, scene.height, args.spp
     tracer = Tracer(local_rank)
@@ -117,15 +132,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    trace("scene uploaded")
     for _ in range(args.warmup):
         step()
+    trace("warm-up issued")
     fence()
+    trace("warm-up done")
     tracer.reset_stats()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    trace("timed steps done")
     st = tracer.stats()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)

@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -72,6 +73,12 @@ struct PtContext {
     PtNormalMode normal_mode = PT_NORMALS_VERTEX;
     int32_t* d_ids = nullptr;
     float* d_t = nullptr;
+    // tile scheduling: per-tile cost of the last dispatch and the order derived from it
+    uint32_t* d_tile_cost = nullptr;
+    uint32_t* d_tile_order = nullptr;
+    int32_t sched_win[4] = {-1, -1, -1, -1};  // window the costs were measured for
+    bool sched_have_cost = false;
+    bool sched_enabled = true;
 
     // uniforms
     PtUniforms uniforms{};
@@ -123,8 +130,12 @@ void free_target(PtContext* ctx) {
     ctx->image_owned = false;
     if (ctx->d_ids) (void)hipFree(ctx->d_ids);
     if (ctx->d_t) (void)hipFree(ctx->d_t);
+    if (ctx->d_tile_cost) (void)hipFree(ctx->d_tile_cost);
+    if (ctx->d_tile_order) (void)hipFree(ctx->d_tile_order);
     ctx->d_ids = nullptr;
     ctx->d_t = nullptr;
+    ctx->d_tile_cost = ctx->d_tile_order = nullptr;
+    ctx->sched_have_cost = false;
     ctx->width = ctx->height = 0;
 }
 
@@ -237,6 +248,9 @@ PtStatus pt_create(int32_t device, PtContext** out_ctx) {
         return fail(PT_ERR_HIP, "context set-up failed: %s", hipGetErrorString(err));
     }
     ctx->stream = ctx->own_stream;
+    // PT_TILE_SCHEDULE=0 renders tiles in raster order (for measuring what the cost-ordered schedule is worth)
+    const char* sched = getenv("PT_TILE_SCHEDULE");
+    ctx->sched_enabled = !(sched && sched[0] == '0');
     *out_ctx = ctx;
     return PT_OK;
 }
@@ -367,6 +381,10 @@ static PtStatus target_common(PtContext* ctx, int32_t width, int32_t height) {
     const size_t n = (size_t)width * height;
     PT_HIP_TRY(hipMalloc(&ctx->d_ids, n * sizeof(int32_t)));
     PT_HIP_TRY(hipMalloc(&ctx->d_t, n * sizeof(float)));
+    const size_t tiles = (size_t)((width + 15) / 16) * ((height + 15) / 16);
+    PT_HIP_TRY(hipMalloc(&ctx->d_tile_cost, tiles * sizeof(uint32_t)));
+    PT_HIP_TRY(hipMalloc(&ctx->d_tile_order, tiles * sizeof(uint32_t)));
+    ctx->sched_have_cost = false;
     return PT_OK;
 }
 
@@ -461,6 +479,23 @@ PtStatus pt_dispatch(PtContext* ctx, int32_t first_sample, int32_t num_samples, 
     const bool partial = ctx->win[2] != ctx->width || ctx->win[3] != ctx->height;
     if (partial && p.dst != p.src) {
         PT_HIP_TRY(hipMemcpyAsync(p.dst, p.src, (size_t)ctx->width * ctx->height * 16, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    // Tile order: the costs measured by the previous dispatch of this same window put the expensive tiles first.
+    // It is only a scheduling hint (any order renders the same image), so stale costs after a camera or scene change
+    // are harmless.
+    if (ctx->sched_enabled) {
+        const int tiles = ((ctx->win[2] + 15) / 16) * ((ctx->win[3] + 15) / 16);
+        const bool same_window = memcmp(ctx->sched_win, ctx->win, sizeof ctx->win) == 0;
+        if (ctx->sched_have_cost && same_window) {
+            PT_HIP_TRY(pt_launch_schedule_tiles(ctx->d_tile_cost, ctx->d_tile_order, tiles, ctx->stream));
+            p.tile_order = ctx->d_tile_order;
+        } else {
+            PT_HIP_TRY(hipMemsetAsync(ctx->d_tile_cost, 0, (size_t)tiles * sizeof(uint32_t), ctx->stream));
+            p.tile_order = nullptr;
+        }
+        p.tile_cost = ctx->d_tile_cost;
+        memcpy(ctx->sched_win, ctx->win, sizeof ctx->win);
+        ctx->sched_have_cost = true;
     }
     if (ctx->timing) {
         s = collect_timing(ctx);

@@ -36,6 +36,8 @@ struct PtKernelParams {
     const float* src;                   // RGBA32F image read (previous result)
     float* dst;                         // RGBA32F image written
     unsigned long long* counters;       // [0] rays, [1] lane slots spent (wave loop trips x 64)
+    const uint32_t* tile_order;         // permutation of the window's 16x16 tiles (block -> tile), or null = identity
+    uint32_t* tile_cost;                // per tile: loop trips spent on it in this dispatch (scheduling hint), or null
     int32_t* out_ids;                   // primary pass only
     float* out_t;                       // primary pass only
 };
@@ -46,4 +48,6 @@ hipError_t pt_launch_prepare_triangles(const float* vertices, const uint32_t* in
                                        hipStream_t stream);
 hipError_t pt_launch_fill_rgba(float* img, size_t num_pixels, float r, float g, float b, float a, hipStream_t stream);
 hipError_t pt_launch_render(const PtKernelParams& p, int program_kind, hipStream_t stream);
+// tile_order <- tiles sorted by descending tile_cost (bucketed); tile_cost <- 0
+hipError_t pt_launch_schedule_tiles(uint32_t* tile_cost, uint32_t* tile_order, int num_tiles, hipStream_t stream);
 hipError_t pt_launch_primary(const PtKernelParams& p, int program_kind, hipStream_t stream);

@@ -240,11 +240,20 @@ __device__ __forceinline__ void shade(Rng& rng, float& energy, v3& rd, v3 N) {
     energy = energy * (diffuse + specular);
 }
 
-__device__ __forceinline__ bool pixel_of_lane(const PtKernelParams& p, int& x, int& y) {
+// Which 16x16 pixel tile this block renders. Blocks are handed to CUs in blockIdx order, so `tile_order` (a permutation
+// of the tile numbers, most expensive first, made from the previous dispatch's per-tile cost) keeps the long tiles from
+// starting last. Any permutation gives the same image.
+__device__ __forceinline__ int tile_of_block(const PtKernelParams& p) {
+    return p.tile_order ? (int)p.tile_order[blockIdx.x] : (int)blockIdx.x;
+}
+
+__device__ __forceinline__ bool pixel_of_lane(const PtKernelParams& p, int tile, int& x, int& y) {
     // 256 threads = 4 waves; a wave covers an 8x8 pixel tile, the block a 16x16 tile.
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int lx = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-    const int ly = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const int tiles_x = (p.win_w + 15) >> 4;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int lx = tx * 16 + (wave & 1) * 8 + (lane & 7);
+    const int ly = ty * 16 + (wave >> 1) * 8 + (lane >> 3);
     x = p.win_x0 + lx;
     y = p.win_y0 + ly;
     return lx < p.win_w && ly < p.win_h;
@@ -278,7 +287,8 @@ __device__ __forceinline__ unsigned __reduce_max_trips(unsigned v) {
 template <int KIND>  // PtProgramKind
 __global__ __launch_bounds__(256) void pt_render_kernel(const PtKernelParams p) {
     int x, y;
-    const bool in_window = pixel_of_lane(p, x, y);
+    const int tile = tile_of_block(p);
+    const bool in_window = pixel_of_lane(p, tile, x, y);
     const size_t pix = in_window ? ((size_t)y * p.width + x) : 0;
     const v3 ro = V(p.ro[0], p.ro[1], p.ro[2]);
 
@@ -346,13 +356,14 @@ __global__ __launch_bounds__(256) void pt_render_kernel(const PtKernelParams p) 
     if ((threadIdx.x & 63) == 0 && wave_rays) {
         atomicAdd(&p.counters[0], wave_rays);
         atomicAdd(&p.counters[1], (unsigned long long)wave_trips * 64ull);
+        if (p.tile_cost) atomicAdd(&p.tile_cost[tile], wave_trips);
     }
 }
 
 template <int KIND>
 __global__ __launch_bounds__(256) void pt_primary_kernel(const PtKernelParams p) {
     int x, y;
-    if (!pixel_of_lane(p, x, y)) return;
+    if (!pixel_of_lane(p, (int)blockIdx.x, x, y)) return;
     const size_t pix = (size_t)y * p.width + x;
     const v3 ro = V(p.ro[0], p.ro[1], p.ro[2]);
     const v3 rd = primary_direction(p, (float)x + 0.5f, (float)y + 0.5f);
@@ -399,7 +410,36 @@ __global__ __launch_bounds__(256) void pt_fill_rgba_kernel(float4* img, size_t n
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) img[i] = value;
 }
 
-dim3 window_grid(const PtKernelParams& p) { return dim3((p.win_w + 15) / 16, (p.win_h + 15) / 16, 1); }
+// Orders the tiles for the next dispatch: most expensive first, by half-octave cost bucket (a counting sort done by
+// one workgroup; slots inside a bucket are handed out atomically, so the result is always a permutation). Also
+// clears the costs for the next accumulation.
+__global__ __launch_bounds__(1024) void pt_schedule_tiles_kernel(uint32_t* __restrict__ cost, uint32_t* __restrict__ order, int n) {
+    __shared__ uint32_t hist[64], start[64];
+    if (threadIdx.x < 64) hist[threadIdx.x] = 0;
+    __syncthreads();
+    auto bucket = [](uint32_t c) -> int {
+        if (c < 2) return (int)c;
+        const int lg = 31 - __builtin_clz(c);
+        const int half = (int)((c >> (lg - 1)) & 1u);
+        const int b = 2 * lg + half;
+        return b > 63 ? 63 : b;
+    };
+    for (int i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&hist[bucket(cost[i])], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (int b = 63; b >= 0; --b) { start[b] = acc; acc += hist[b]; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t slot = atomicAdd(&start[bucket(cost[i])], 1u);
+        order[slot] = (uint32_t)i;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) cost[i] = 0;
+}
+
+int window_tiles(const PtKernelParams& p) { return ((p.win_w + 15) / 16) * ((p.win_h + 15) / 16); }
 
 }  // namespace
 
@@ -420,16 +460,22 @@ hipError_t pt_launch_fill_rgba(float* img, size_t num_pixels, float r, float g, 
     return hipGetLastError();
 }
 
+hipError_t pt_launch_schedule_tiles(uint32_t* tile_cost, uint32_t* tile_order, int num_tiles, hipStream_t stream) {
+    if (num_tiles <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pt_schedule_tiles_kernel, dim3(1), dim3(1024), 0, stream, tile_cost, tile_order, num_tiles);
+    return hipGetLastError();
+}
+
 hipError_t pt_launch_render(const PtKernelParams& p, int program_kind, hipStream_t stream) {
     if (p.win_w <= 0 || p.win_h <= 0 || p.num_samples <= 0) return hipSuccess;
-    if (program_kind == 0) hipLaunchKernelGGL(pt_render_kernel<0>, window_grid(p), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL(pt_render_kernel<1>, window_grid(p), dim3(256), 0, stream, p);
+    if (program_kind == 0) hipLaunchKernelGGL(pt_render_kernel<0>, dim3(window_tiles(p)), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(pt_render_kernel<1>, dim3(window_tiles(p)), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 
 hipError_t pt_launch_primary(const PtKernelParams& p, int program_kind, hipStream_t stream) {
     if (p.win_w <= 0 || p.win_h <= 0) return hipSuccess;
-    if (program_kind == 0) hipLaunchKernelGGL(pt_primary_kernel<0>, window_grid(p), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL(pt_primary_kernel<1>, window_grid(p), dim3(256), 0, stream, p);
+    if (program_kind == 0) hipLaunchKernelGGL(pt_primary_kernel<0>, dim3(window_tiles(p)), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(pt_primary_kernel<1>, dim3(window_tiles(p)), dim3(256), 0, stream, p);
     return hipGetLastError();
 }

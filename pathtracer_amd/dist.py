@@ -37,11 +37,22 @@ def row_blocks(rank, world, height, block=16):
     return out
 
 
+def _all_reduce_sum(t, group=None):
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return
+    if t.is_cuda and dist.get_backend(group) != "nccl":
+        # CPU-side backends (gloo rehearsals on a one-GPU box): stage through host memory
+        host = t.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)  # RCCL over xGMI on the GPU box
+
+
 def merge_sample_split(sum_image, total_samples, group=None):
     """In-place all-reduce of the per-rank running sums, then scale to the mean. `sum_image`: [H, W, 4] fp32 tensor
     whose rgb holds this rank's sum; alpha is overwritten with 1."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(sum_image, op=dist.ReduceOp.SUM, group=group)
+    _all_reduce_sum(sum_image, group)
     sum_image.mul_(1.0 / float(total_samples))
     sum_image[..., 3] = 1.0
     return sum_image
@@ -50,8 +61,7 @@ def merge_sample_split(sum_image, total_samples, group=None):
 def merge_tile_split(image, height, block=16, group=None):
     """Every rank ends up with the full image: rows it does not own are zero before the call, so a sum all-reduce
     moves each row from its owner to everyone without changing a bit (x + 0 + ... + 0 is exact)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(image, op=dist.ReduceOp.SUM, group=group)
+    _all_reduce_sum(image, group)
     return image
 
 

@@ -28,14 +28,16 @@ def main():
     t.dispatch(1, 1, 1)
     t.finish()
     t.reset_stats()
+    per_rep = []
     for _ in range(args.reps):
         t.target_clear()
         t.dispatch(1, args.spp, 1)
         t.finish()
+        per_rep.append(round(t.stats()["last_dispatch_ms"], 3))
     st = t.stats()
     ms = st["total_dispatch_ms"] / st["dispatches"]
     print(json.dumps({"workload": args.workload, "size": [scene.width, scene.height], "spp": args.spp, "triangles": scene.num_triangles,
-                      "kernel_ms": ms, "Grays_per_s": st["rays"] / st["dispatches"] / ms * 1e-6,
+                      "kernel_ms": ms, "per_rep_ms": per_rep, "Grays_per_s": st["rays"] / st["dispatches"] / ms * 1e-6,
                       "rays_per_sample": st["rays"] / st["samples"], "lane_utilisation": st["rays"] / st["lane_slots"]}))
     t.close()
 
