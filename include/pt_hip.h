@@ -54,6 +54,13 @@ typedef enum PtNormalMode {
                                 bounds, PathTracer.cpp:1191-1193) */
 } PtNormalMode;
 
+/* How the closest mesh hit is searched. Results are identical in every mode (same triangle ids, same distances). */
+typedef enum PtAccelMode {
+    PT_ACCEL_AUTO = 0,  /* use the LBVH when one has been built (pt_build_accel), else test every triangle */
+    PT_ACCEL_BRUTE = 1, /* the shader's own loop over all triangles in index order, pathtracing.fs:129 */
+    PT_ACCEL_BVH = 2    /* require the LBVH: pt_dispatch fails with PT_ERR_STATE when none is built */
+} PtAccelMode;
+
 /* How a dispatch folds a sample into the target. */
 typedef enum PtAccumMode {
     PT_ACCUM_MEAN = 0, /* out = prev + (1/u_Samples)*(sample - prev): the shader's mix(), pathtracing.fs:414 */
@@ -126,6 +133,11 @@ PtStatus pt_upload_materials(PtContext* ctx, const float* rgbt, int32_t count);
 PtStatus pt_upload_mesh(PtContext* ctx, const float* vertices, int32_t num_vertices, const uint32_t* indices,
                         int32_t num_triangles);
 PtStatus pt_set_normal_mode(PtContext* ctx, PtNormalMode mode);
+/* Builds a linear BVH over the uploaded mesh on the device (Morton codes, radix sort, Karras hierarchy, bottom-up
+ * boxes). No counterpart in the reference, whose shader tests every triangle for every ray; needed for scenes beyond a
+ * few thousand triangles. A new pt_upload_mesh discards it. Meshes of at most 4 triangles need none (PT_OK, no-op). */
+PtStatus pt_build_accel(PtContext* ctx);
+PtStatus pt_set_accel_mode(PtContext* ctx, PtAccelMode mode);
 
 /* ---- accumulation target: replaces the two RGBA32F textures + FBOs (PathTracer.cpp:1136-1152) ------------ */
 

@@ -16,6 +16,7 @@ PT_ERR_INVALID_ARGUMENT, PT_ERR_HIP, PT_ERR_STATE, PT_ERR_NO_DEVICE, PT_ERR_UNSU
 PROGRAM_WORLD, PROGRAM_MESH = 0, 1
 NORMALS_VERTEX, NORMALS_GEOMETRIC = 0, 1
 ACCUM_MEAN, ACCUM_SUM = 0, 1
+ACCEL_AUTO, ACCEL_BRUTE, ACCEL_BVH = 0, 1, 2
 
 
 class PtUniforms(C.Structure):
@@ -50,6 +51,8 @@ SIGNATURES = {
     "pt_upload_materials": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "pt_upload_mesh": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),
     "pt_set_normal_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "pt_build_accel": (C.c_int, [C.c_void_p]),
+    "pt_set_accel_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "pt_target_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "pt_target_bind_external": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     "pt_target_clear": (C.c_int, [C.c_void_p]),
@@ -150,6 +153,12 @@ class Tracer:
         v = np.ascontiguousarray(vertices, np.float32).reshape(-1, 6)
         i = np.ascontiguousarray(indices, np.uint32).reshape(-1, 3)
         check(self._lib.pt_upload_mesh(self._ctx, v.ctypes.data, len(v), i.ctypes.data, len(i)), self._lib)
+
+    def build_accel(self):
+        check(self._lib.pt_build_accel(self._ctx), self._lib)
+
+    def set_accel_mode(self, mode):
+        check(self._lib.pt_set_accel_mode(self._ctx, mode), self._lib)
 
     def set_normal_mode(self, mode):
         check(self._lib.pt_set_normal_mode(self._ctx, mode), self._lib)

@@ -1,0 +1,243 @@
+// Device-built LBVH over the mesh (Morton codes -> radix sort -> Karras hierarchy -> refit), emitted as 64-byte
+// "two children per record" nodes for wave-coherent traversal. The reference has no acceleration structure (its
+// shader loops over every triangle, pathtracing.fs:129); this one exists so that scenes far beyond a few thousand
+// triangles are traceable, and it must not change a single result: traversal (pt_kernels.hip) only ever SKIPS triangles
+// that the exact test could not accept, and resolves equal distances by the lowest triangle index, which is what the
+// shader's ascending loop with a strict '<' does.
+#include "pt_internal.h"
+
+#include <hipcub/hipcub.hpp>
+
+namespace {
+
+// ---- order-preserving float <-> uint mapping for atomic min/max -------------------------------------------------
+__device__ __forceinline__ uint32_t f2ord(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t o) {
+    return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+
+__device__ __forceinline__ uint32_t spread10(uint32_t v) {  // 10 bits -> every third bit
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+
+__global__ __launch_bounds__(256) void bvh_init_scene_box(uint32_t* scene_box) {
+    if (threadIdx.x < 3) scene_box[threadIdx.x] = 0xffffffffu;       // min
+    else if (threadIdx.x < 6) scene_box[threadIdx.x] = 0u;           // max
+}
+
+// per triangle: absolute box (6 floats); scene box of the centroids by atomics (one per wave would be nicer; n is small
+// next to the render work)
+__global__ __launch_bounds__(256) void bvh_tri_boxes(const float* __restrict__ vertices, const uint32_t* __restrict__ indices, int n,
+                                                     float* __restrict__ tri_box, uint32_t* __restrict__ scene_box) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* a = vertices + 6 * (size_t)indices[3 * i];
+    const float* b = vertices + 6 * (size_t)indices[3 * i + 1];
+    const float* c = vertices + 6 * (size_t)indices[3 * i + 2];
+    float lo[3], hi[3];
+    for (int k = 0; k < 3; ++k) {
+        lo[k] = fminf(a[k], fminf(b[k], c[k]));
+        hi[k] = fmaxf(a[k], fmaxf(b[k], c[k]));
+        tri_box[6 * (size_t)i + k] = lo[k];
+        tri_box[6 * (size_t)i + 3 + k] = hi[k];
+        const float ctr = 0.5f * lo[k] + 0.5f * hi[k];
+        atomicMin(&scene_box[k], f2ord(ctr));
+        atomicMax(&scene_box[3 + k], f2ord(ctr));
+    }
+}
+
+// key = 30-bit Morton code of the centroid (high word) | triangle index (low word): unique, so the hierarchy is well defined
+__global__ __launch_bounds__(256) void bvh_morton_keys(const float* __restrict__ tri_box, const uint32_t* __restrict__ scene_box, int n,
+                                                       unsigned long long* __restrict__ keys) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t q[3];
+    for (int k = 0; k < 3; ++k) {
+        const float lo = ord2f(scene_box[k]), hi = ord2f(scene_box[3 + k]);
+        const float ctr = 0.5f * tri_box[6 * (size_t)i + k] + 0.5f * tri_box[6 * (size_t)i + 3 + k];
+        const float ext = hi - lo;
+        float u = ext > 0.f ? (ctr - lo) / ext : 0.f;
+        u = fminf(fmaxf(u * 1024.f, 0.f), 1023.f);
+        q[k] = (uint32_t)u;
+    }
+    const uint32_t code = (spread10(q[0]) << 2) | (spread10(q[1]) << 1) | spread10(q[2]);
+    keys[i] = ((unsigned long long)code << 32) | (uint32_t)i;
+}
+
+__device__ __forceinline__ int key_delta(const unsigned long long* __restrict__ keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    return __builtin_clzll(keys[i] ^ keys[j]);  // keys are distinct
+}
+
+// Karras 2012: internal node i of n-1. child refs: >= 0 internal node index; < 0 leaf at sorted position ~ref.
+__global__ __launch_bounds__(256) void bvh_hierarchy(const unsigned long long* __restrict__ keys, int n, int* __restrict__ child,
+                                                     int* __restrict__ range) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    const int d = key_delta(keys, n, i, i + 1) > key_delta(keys, n, i, i - 1) ? 1 : -1;
+    const int dmin = key_delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (key_delta(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2)
+        if (key_delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = key_delta(keys, n, i, j);
+    int s = 0;
+    for (int t = (l + 1) / 2;; t = (t + 1) / 2) {
+        if (key_delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+        if (t == 1) break;
+    }
+    const int gamma = i + s * d + (d < 0 ? -1 : 0);
+    const int first = i < j ? i : j, last = i < j ? j : i;
+    child[2 * i] = first == gamma ? ~gamma : gamma;
+    child[2 * i + 1] = last == gamma + 1 ? ~(gamma + 1) : gamma + 1;
+    range[2 * i] = first;
+    range[2 * i + 1] = last;
+}
+
+// One bottom-up sweep: computes the box of every node whose children were finished by an EARLIER launch (done[c] in
+// [1, pass)). Kernel boundaries provide the visibility between sweeps; nothing is handed over inside a launch.
+__global__ __launch_bounds__(256) void bvh_refit_pass(const unsigned long long* __restrict__ keys, const int* __restrict__ child,
+                                                      const float* __restrict__ tri_box, int n, int pass, float* __restrict__ node_box,
+                                                      int* __restrict__ done, int* __restrict__ remaining) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1 || done[i] != 0) return;
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int c = 0; c < 2; ++c) {
+        const int ref = child[2 * i + c];
+        const float* box;
+        if (ref < 0) {
+            box = tri_box + 6 * (size_t)(uint32_t)(keys[~ref] & 0xffffffffull);
+        } else {
+            const int dn = done[ref];
+            if (dn == 0 || dn >= pass) return;
+            box = node_box + 6 * (size_t)ref;
+        }
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = fminf(lo[k], box[k]);
+            hi[k] = fmaxf(hi[k], box[3 + k]);
+        }
+    }
+    for (int k = 0; k < 3; ++k) {
+        node_box[6 * (size_t)i + k] = lo[k];
+        node_box[6 * (size_t)i + 3 + k] = hi[k];
+    }
+    done[i] = pass;
+    atomicSub(remaining, 1);
+}
+
+// Reference to a child as the traversal sees it: subtrees of at most PT_BVH_LEAF_MAX triangles are leaves
+// (0x80000000 | first << 3 | count-1, sorted positions), everything else an internal node index.
+__device__ __forceinline__ uint32_t traversal_ref(int ref, const int* __restrict__ range) {
+    if (ref < 0) return 0x80000000u | ((uint32_t)(~ref) << 3);
+    const int first = range[2 * ref], count = range[2 * ref + 1] - first + 1;
+    if (count <= PT_BVH_LEAF_MAX) return 0x80000000u | ((uint32_t)first << 3) | (uint32_t)(count - 1);
+    return (uint32_t)ref;
+}
+
+// Traversal record of internal node i: both children's boxes, relative to the ray origin (all rays share it) and
+// padded so that a ray the exact fp32 triangle test accepts can never fail the box test through rounding:
+// the slab arithmetic errs by ~1e-7 relative to the distance from the origin; the pad is 1e-5 of it.
+__global__ __launch_bounds__(256) void bvh_emit_nodes(const unsigned long long* __restrict__ keys, const int* __restrict__ child,
+                                                      const int* __restrict__ range, const float* __restrict__ tri_box,
+                                                      const float* __restrict__ node_box, int n, float rox, float roy, float roz,
+                                                      float* __restrict__ nodes) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    const float ro[3] = {rox, roy, roz};
+    float* out = nodes + (size_t)i * PT_BVH_NODE_FLOATS;
+    for (int c = 0; c < 2; ++c) {
+        const int ref = child[2 * i + c];
+        const float* box = ref < 0 ? tri_box + 6 * (size_t)(uint32_t)(keys[~ref] & 0xffffffffull) : node_box + 6 * (size_t)ref;
+        float rel[6], far = 0.f;
+        for (int k = 0; k < 3; ++k) {
+            rel[k] = box[k] - ro[k];
+            rel[3 + k] = box[3 + k] - ro[k];
+            far = fmaxf(far, fmaxf(fabsf(rel[k]), fabsf(rel[3 + k])));
+        }
+        const float pad = 1.0e-5f * far + 1.0e-30f;
+        for (int k = 0; k < 3; ++k) {
+            out[6 * c + k] = rel[k] - pad;
+            out[6 * c + 3 + k] = rel[3 + k] + pad;
+        }
+        out[12 + c] = __uint_as_float(traversal_ref(ref, range));
+    }
+    out[14] = 0.f;
+    out[15] = 0.f;
+}
+
+// Triangle records and ids in sorted (leaf) order; the tail is padded with all-zero records like the unsorted array.
+__global__ __launch_bounds__(256) void bvh_gather_records(const unsigned long long* __restrict__ keys, const float4* __restrict__ tris, int n,
+                                                          float4* __restrict__ sorted_tris, int* __restrict__ sorted_ids) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n + PT_TRI_PAD) return;
+    if (k < n) {
+        const uint32_t id = (uint32_t)(keys[k] & 0xffffffffull);
+        for (int q = 0; q < 4; ++q) sorted_tris[4 * (size_t)k + q] = tris[4 * (size_t)id + q];
+        sorted_ids[k] = (int)id;
+    } else {
+        for (int q = 0; q < 4; ++q) sorted_tris[4 * (size_t)k + q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        sorted_ids[k] = 0x7fffffff;
+    }
+}
+
+inline dim3 grid_for(int n) { return dim3((unsigned)((n + 255) / 256)); }
+
+}  // namespace
+
+size_t pt_bvh_sort_temp_bytes(int32_t n) {
+    size_t bytes = 0;
+    (void)hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, n, 0, 64, nullptr);
+    return bytes;
+}
+
+hipError_t pt_bvh_build_topology(const PtBvhBuild& b, hipStream_t stream, int32_t* out_passes) {
+    const int n = b.num_triangles;
+    if (out_passes) *out_passes = 0;
+    if (n < 2) return hipSuccess;
+    hipLaunchKernelGGL(bvh_init_scene_box, dim3(1), dim3(64), 0, stream, b.scene_box);
+    hipLaunchKernelGGL(bvh_tri_boxes, grid_for(n), dim3(256), 0, stream, b.vertices, b.indices, n, b.tri_box, b.scene_box);
+    hipLaunchKernelGGL(bvh_morton_keys, grid_for(n), dim3(256), 0, stream, b.tri_box, b.scene_box, n, b.keys_tmp);
+    size_t bytes = b.sort_tmp_bytes;
+    hipError_t e = hipcub::DeviceRadixSort::SortKeys(b.sort_tmp, bytes, b.keys_tmp, b.keys, n, 0, 64, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(bvh_hierarchy, grid_for(n - 1), dim3(256), 0, stream, b.keys, n, b.child, b.range);
+    e = hipMemsetAsync(b.done, 0, (size_t)(n - 1) * sizeof(int), stream);
+    if (e != hipSuccess) return e;
+    int remaining = n - 1;
+    e = hipMemcpyAsync(b.remaining, &remaining, sizeof(int), hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return e;
+    // The tree height is at most 64 + log2(n) sweeps-worth (64-bit distinct keys); sweeps run in groups of 8 between checks.
+    int pass = 1;
+    while (remaining > 0) {
+        if (pass > 4096) return hipErrorUnknown;  // cannot happen for a well-formed hierarchy; never spin forever
+        for (int g = 0; g < 8; ++g, ++pass)
+            hipLaunchKernelGGL(bvh_refit_pass, grid_for(n - 1), dim3(256), 0, stream, b.keys, b.child, b.tri_box, n, pass + 1, b.node_box,
+                               b.done, b.remaining);
+        e = hipMemcpyAsync(&remaining, b.remaining, sizeof(int), hipMemcpyDeviceToHost, stream);
+        if (e != hipSuccess) return e;
+        e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) return e;
+    }
+    if (out_passes) *out_passes = pass - 1;
+    return hipGetLastError();
+}
+
+hipError_t pt_bvh_emit(const PtBvhBuild& b, const float ro[3], const float* tris, hipStream_t stream) {
+    const int n = b.num_triangles;
+    if (n < 1) return hipSuccess;
+    if (n >= 2)
+        hipLaunchKernelGGL(bvh_emit_nodes, grid_for(n - 1), dim3(256), 0, stream, b.keys, b.child, b.range, b.tri_box, b.node_box, n, ro[0],
+                           ro[1], ro[2], b.nodes);
+    hipLaunchKernelGGL(bvh_gather_records, grid_for(n + PT_TRI_PAD), dim3(256), 0, stream, b.keys, reinterpret_cast<const float4*>(tris), n,
+                       reinterpret_cast<float4*>(b.sorted_tris), b.sorted_ids);
+    return hipGetLastError();
+}

@@ -62,6 +62,11 @@ struct PtContext {
     float* d_gnormals = nullptr;
     bool records_valid = false;
     float records_ro[3] = {0, 0, 0};
+    // LBVH (optional)
+    PtBvhBuild bvh{};
+    bool bvh_built = false;
+    int32_t bvh_refit_passes = 0;
+    PtAccelMode accel_mode = PT_ACCEL_AUTO;
 
     // target
     float* d_image[2] = {nullptr, nullptr};
@@ -139,7 +144,18 @@ void free_target(PtContext* ctx) {
     ctx->width = ctx->height = 0;
 }
 
+void free_bvh(PtContext* ctx) {
+    PtBvhBuild& b = ctx->bvh;
+    void* ptrs[] = {b.tri_box, b.scene_box, b.keys_tmp, b.keys, b.sort_tmp, b.child, b.range, b.node_box, b.done, b.remaining,
+                    b.nodes, b.sorted_tris, b.sorted_ids};
+    for (void* q : ptrs)
+        if (q) (void)hipFree(q);
+    b = PtBvhBuild{};
+    ctx->bvh_built = false;
+}
+
 void free_mesh(PtContext* ctx) {
+    free_bvh(ctx);
     float** f[] = {&ctx->d_vertices, &ctx->d_tris, &ctx->d_vnormals, &ctx->d_gnormals};
     for (float** q : f) {
         if (*q) (void)hipFree(*q);
@@ -157,6 +173,8 @@ PtStatus ensure_records(PtContext* ctx) {
     if (ctx->records_valid && memcmp(ro, ctx->records_ro, sizeof ctx->records_ro) == 0) return PT_OK;
     PT_HIP_TRY(pt_launch_prepare_triangles(ctx->d_vertices, ctx->d_indices, ctx->num_triangles, ro, ctx->d_tris,
                                            ctx->d_vnormals, ctx->d_gnormals, ctx->stream));
+    // the BVH's boxes and leaf-order records are expressed relative to the ray origin too
+    if (ctx->bvh_built) PT_HIP_TRY(pt_bvh_emit(ctx->bvh, ro, ctx->d_tris, ctx->stream));
     memcpy(ctx->records_ro, ro, sizeof ctx->records_ro);
     ctx->records_valid = true;
     return PT_OK;
@@ -191,6 +209,19 @@ PtStatus fill_params(PtContext* ctx, PtKernelParams* p, const Program** prog_out
         p->tris = ctx->d_tris;
         p->vnormals = ctx->d_vnormals;
         p->gnormals = ctx->d_gnormals;
+        PT_REQUIRE(ctx->accel_mode != PT_ACCEL_BVH || ctx->bvh_built, PT_ERR_STATE, "PT_ACCEL_BVH but no BVH: call pt_build_accel first");
+        // the hierarchy covers the whole mesh, so it serves only when every uploaded triangle is traced
+        // and in AUTO mode only when the mesh is big enough for the walk to beat the plain loop (36 triangles: the
+        // loop is 15 % faster; 968: the BVH is 6x faster)
+        const bool use_bvh = ctx->bvh_built && ctx->accel_mode != PT_ACCEL_BRUTE && u.num_triangles == ctx->num_triangles &&
+                             (ctx->accel_mode == PT_ACCEL_BVH || u.num_triangles > PT_BVH_AUTO_MIN_TRIANGLES);
+        PT_REQUIRE(use_bvh || ctx->accel_mode != PT_ACCEL_BVH, PT_ERR_STATE, "the BVH covers all %d triangles but u_NumTriangles = %d",
+                   ctx->num_triangles, u.num_triangles);
+        if (use_bvh) {
+            p->bvh_nodes = ctx->bvh.nodes;
+            p->bvh_tris = ctx->bvh.sorted_tris;
+            p->bvh_ids = ctx->bvh.sorted_ids;
+        }
     } else {
         PT_REQUIRE(ctx->have_spheres, PT_ERR_STATE, "no spheres uploaded: call pt_upload_spheres first");
         p->spheres = ctx->d_spheres;
@@ -363,6 +394,54 @@ PtStatus pt_upload_mesh(PtContext* ctx, const float* vertices, int32_t num_verti
     ctx->num_vertices = num_vertices;
     ctx->num_triangles = num_triangles;
     ctx->records_valid = false;
+    return PT_OK;
+}
+
+PtStatus pt_build_accel(PtContext* ctx) {
+    PtStatus s = bind(ctx);
+    if (s != PT_OK) return s;
+    PT_REQUIRE(ctx->num_triangles > 0, PT_ERR_STATE, "no mesh uploaded");
+    PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    free_bvh(ctx);
+    const int32_t n = ctx->num_triangles;
+    if (n <= PT_BVH_LEAF_MAX) return PT_OK;  // a single leaf: the plain loop is the traversal
+    PtBvhBuild& b = ctx->bvh;
+    b.num_triangles = n;
+    b.vertices = ctx->d_vertices;
+    b.indices = ctx->d_indices;
+    const size_t nn = (size_t)n, ni = (size_t)(n - 1);
+    b.sort_tmp_bytes = pt_bvh_sort_temp_bytes(n);
+    hipError_t e = hipSuccess;
+    auto alloc = [&e](auto** ptr, size_t bytes) {
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(ptr), bytes ? bytes : 16);
+    };
+    alloc(&b.tri_box, nn * 6 * sizeof(float));
+    alloc(&b.scene_box, 6 * sizeof(uint32_t));
+    alloc(&b.keys_tmp, nn * sizeof(unsigned long long));
+    alloc(&b.keys, nn * sizeof(unsigned long long));
+    alloc(&b.sort_tmp, b.sort_tmp_bytes);
+    alloc(&b.child, ni * 2 * sizeof(int));
+    alloc(&b.range, ni * 2 * sizeof(int));
+    alloc(&b.node_box, ni * 6 * sizeof(float));
+    alloc(&b.done, ni * sizeof(int));
+    alloc(&b.remaining, sizeof(int));
+    alloc(&b.nodes, ni * PT_BVH_NODE_FLOATS * sizeof(float));
+    alloc(&b.sorted_tris, (nn + PT_TRI_PAD) * PT_TRI_FLOATS * sizeof(float));
+    alloc(&b.sorted_ids, (nn + PT_TRI_PAD) * sizeof(int));
+    if (e == hipSuccess) e = pt_bvh_build_topology(b, ctx->stream, &ctx->bvh_refit_passes);
+    if (e != hipSuccess) {
+        free_bvh(ctx);
+        return fail(PT_ERR_HIP, "BVH build failed: %s", hipGetErrorString(e));
+    }
+    ctx->bvh_built = true;
+    ctx->records_valid = false;  // leaf-order records and origin-relative boxes are emitted with the next records
+    return PT_OK;
+}
+
+PtStatus pt_set_accel_mode(PtContext* ctx, PtAccelMode mode) {
+    PT_REQUIRE(ctx != nullptr, PT_ERR_INVALID_ARGUMENT, "null context");
+    PT_REQUIRE(mode == PT_ACCEL_AUTO || mode == PT_ACCEL_BRUTE || mode == PT_ACCEL_BVH, PT_ERR_INVALID_ARGUMENT, "unknown accel mode %d", (int)mode);
+    ctx->accel_mode = mode;
     return PT_OK;
 }
 

@@ -21,6 +21,41 @@ struct PtTriRecordLayout {
     enum { E1 = 0, E2 = 3, AP = 6, R = 9, E2R = 12 };
 };
 
+// LBVH: traversal record of one internal node, 16 floats = 64 bytes (one scalar fetch):
+//   [0..5] left child box min/max, [6..11] right child box min/max -- relative to the ray origin, padded
+//   [12] left ref, [13] right ref (uint bits): 0x80000000 | first << 3 | count-1 = leaf of `count` triangles starting
+//   at sorted position `first`; otherwise the index of an internal node.
+#define PT_BVH_NODE_FLOATS 16
+#define PT_BVH_LEAF_MAX 4
+#define PT_BVH_STACK 96
+#define PT_BVH_AUTO_MIN_TRIANGLES 128
+
+struct PtBvhBuild {
+    int32_t num_triangles;
+    const float* vertices;        // raw upload (6 floats per vertex)
+    const uint32_t* indices;      // raw upload
+    float* tri_box;               // n x 6, absolute, original triangle order
+    uint32_t* scene_box;          // 6 order-preserving uints: centroid bounds
+    unsigned long long* keys_tmp; // n
+    unsigned long long* keys;     // n, sorted: Morton code << 32 | triangle id
+    void* sort_tmp;
+    size_t sort_tmp_bytes;
+    int* child;                   // (n-1) x 2
+    int* range;                   // (n-1) x 2: first,last sorted position
+    float* node_box;              // (n-1) x 6, absolute
+    int* done;                    // (n-1): refit sweep in which the node was finished
+    int* remaining;               // 1
+    float* nodes;                 // (n-1) x PT_BVH_NODE_FLOATS traversal records
+    float* sorted_tris;           // (n + PT_TRI_PAD) x PT_TRI_FLOATS
+    int* sorted_ids;              // n + PT_TRI_PAD
+};
+
+size_t pt_bvh_sort_temp_bytes(int32_t n);
+// Morton codes, sort, hierarchy, boxes. Synchronises the stream (a handful of times) to learn when the refit is done.
+hipError_t pt_bvh_build_topology(const PtBvhBuild& b, hipStream_t stream, int32_t* out_passes);
+// Traversal records for ray origin `ro` + triangle records/ids in leaf order (from the per-triangle records `tris`).
+hipError_t pt_bvh_emit(const PtBvhBuild& b, const float ro[3], const float* tris, hipStream_t stream);
+
 struct PtKernelParams {
     float ro[3], llc[3], hor[3], ver[3];
     int32_t width, height;              // full frame: textureSize(u_Texture, 0)
@@ -32,6 +67,9 @@ struct PtKernelParams {
     const float* tris;                  // num_triangles x PT_TRI_FLOATS
     const float* vnormals;              // num_triangles x 9: the three vertex normals (na, nb, nc)
     const float* gnormals;              // num_triangles x 3: normalize(cross(e1, e2))
+    const float* bvh_nodes;             // LBVH traversal records, or null = test every triangle in index order
+    const float* bvh_tris;              // triangle records in leaf order
+    const int32_t* bvh_ids;             // triangle id of each leaf-order record
     const float* spheres;               // 10 x (cx, cy, cz, r)
     const float* src;                   // RGBA32F image read (previous result)
     float* dst;                         // RGBA32F image written

@@ -121,6 +121,7 @@ struct Hit {
 // (see pt_internal.h). The record registers are wave-uniform (scalar).
 struct TriRec { float4 a, b, c, d; };  // e1.xyz e2.x | e2.yz ap.xy | ap.z r.xyz | e2r - - -
 
+template <bool ANY_ORDER>
 __device__ __forceinline__ void test_triangle(const TriRec& t, int id, v3 rd, Hit& h) {
     const v3 e1 = V(t.a.x, t.a.y, t.a.z);
     const v3 e2 = V(t.a.w, t.b.x, t.b.y);
@@ -139,7 +140,10 @@ __device__ __forceinline__ void test_triangle(const TriRec& t, int id, v3 rd, Hi
     if (inside) {
         const float ood = 1.0f / det;
         const float tt = t.d.x * ood;
-        if (tt > 0.0f && tt < h.t) {  // strict '<' in ascending id: the lowest index wins ties
+        // The shader visits triangles in ascending id with a strict '<', so among equal distances the lowest id wins.
+        // When triangles arrive in another order (BVH leaves) that rule is applied explicitly.
+        const bool closer = ANY_ORDER ? (tt < h.t || (tt == h.t && id < h.id)) : (tt < h.t);
+        if (tt > 0.0f && closer) {
             h.t = tt; h.id = id; h.u = u; h.v = v; h.ood = ood;
         }
     }
@@ -160,19 +164,80 @@ __device__ __forceinline__ Hit intersect_mesh(const float* __restrict__ tris, in
     h.t = 1.0e38f; h.id = -1; h.u = 0.f; h.v = 0.f; h.ood = 0.f;
     const float4* __restrict__ recs = reinterpret_cast<const float4*>(tris);
 #ifdef PT_V_SIMPLE
-    for (int i = 0; i < n; ++i) test_triangle(load_rec(recs, i), i, rd, h);
+    for (int i = 0; i < n; ++i) test_triangle<false>(load_rec(recs, i), i, rd, h);
 #else
     TriRec a0 = load_rec(recs, 0), a1 = load_rec(recs, 1);
     for (int i = 0; i < n; i += 4) {
         const TriRec b0 = load_rec(recs, i + 2), b1 = load_rec(recs, i + 3);
-        test_triangle(a0, i, rd, h);
-        test_triangle(a1, i + 1, rd, h);
+        test_triangle<false>(a0, i, rd, h);
+        test_triangle<false>(a1, i + 1, rd, h);
         a0 = load_rec(recs, i + 4);
         a1 = load_rec(recs, i + 5);
-        test_triangle(b0, i + 2, rd, h);
-        test_triangle(b1, i + 3, rd, h);
+        test_triangle<false>(b0, i + 2, rd, h);
+        test_triangle<false>(b1, i + 3, rd, h);
     }
 #endif
+    return h;
+}
+
+// Closest hit through the LBVH, one traversal per WAVE: the stack and the node being visited are wave-uniform (node
+// records arrive by scalar loads), each lane tests its own ray against the two child boxes, and a child is entered when
+// ANY lane may hit it. Rays of a wave are coherent (an 8x8 pixel tile and its near-mirror bounces), so the union of
+// their paths through the tree is short. A lane's box test passes when its ray can reach the padded box no farther than
+// its current hit (equal distance included, so a lower-id triangle at the same distance is still found); leaves run
+// the exact triangle test with the explicit lowest-id rule. The result equals the all-triangles loop bit for bit.
+__device__ __forceinline__ Hit intersect_bvh(const PtKernelParams& p, v3 rd, uint32_t* __restrict__ stack) {
+    Hit h;
+    h.t = 1.0e38f; h.id = -1; h.u = 0.f; h.v = 0.f; h.ood = 0.f;
+    // Reciprocal direction for the slab tests only (culling arithmetic is not part of the reference's numerics; it
+    // only has to be conservative, which the padded boxes and the slack on `limit` guarantee). A zero component is
+    // replaced by a tiny one of the same sign: the slab test then degenerates to "origin inside the slab".
+    const float tiny = 1.0e-30f;
+    const float ix = __builtin_amdgcn_rcpf(__builtin_fabsf(rd.x) > tiny ? rd.x : __builtin_copysignf(tiny, rd.x));
+    const float iy = __builtin_amdgcn_rcpf(__builtin_fabsf(rd.y) > tiny ? rd.y : __builtin_copysignf(tiny, rd.y));
+    const float iz = __builtin_amdgcn_rcpf(__builtin_fabsf(rd.z) > tiny ? rd.z : __builtin_copysignf(tiny, rd.z));
+    const float4* __restrict__ nodes = reinterpret_cast<const float4*>(p.bvh_nodes);
+    const float4* __restrict__ recs = reinterpret_cast<const float4*>(p.bvh_tris);
+    uint32_t ref = 0;  // root = internal node 0
+    int sp = 0;
+    for (;;) {
+        if (ref & 0x80000000u) {
+            const int first = (int)((ref & 0x7fffffffu) >> 3), count = (int)(ref & 7u) + 1;
+            for (int k = 0; k < count; ++k) test_triangle<true>(load_rec(recs, first + k), p.bvh_ids[first + k], rd, h);
+        } else {
+            const float4 n0 = nodes[4 * (size_t)ref], n1 = nodes[4 * (size_t)ref + 1], n2 = nodes[4 * (size_t)ref + 2],
+                         n3 = nodes[4 * (size_t)ref + 3];
+            const float limit = h.t * 1.0001f;
+            // left box: n0.xyz = min, (n0.w, n1.x, n1.y) = max; right box: (n1.z, n1.w, n2.x) = min, n2.yzw = max
+            float a, b;
+            a = n0.x * ix; b = n0.w * ix; float lnear = __builtin_fminf(a, b), lfar = __builtin_fmaxf(a, b);
+            a = n0.y * iy; b = n1.x * iy; lnear = __builtin_fmaxf(lnear, __builtin_fminf(a, b)); lfar = __builtin_fminf(lfar, __builtin_fmaxf(a, b));
+            a = n0.z * iz; b = n1.y * iz; lnear = __builtin_fmaxf(lnear, __builtin_fminf(a, b)); lfar = __builtin_fminf(lfar, __builtin_fmaxf(a, b));
+            a = n1.z * ix; b = n2.y * ix; float rnear = __builtin_fminf(a, b), rfar = __builtin_fmaxf(a, b);
+            a = n1.w * iy; b = n2.z * iy; rnear = __builtin_fmaxf(rnear, __builtin_fminf(a, b)); rfar = __builtin_fminf(rfar, __builtin_fmaxf(a, b));
+            a = n2.x * iz; b = n2.w * iz; rnear = __builtin_fmaxf(rnear, __builtin_fminf(a, b)); rfar = __builtin_fminf(rfar, __builtin_fmaxf(a, b));
+            const bool hl = (lnear <= lfar) & (lfar >= 0.0f) & (lnear <= limit);
+            const bool hr = (rnear <= rfar) & (rfar >= 0.0f) & (rnear <= limit);
+            const unsigned long long ml = __builtin_amdgcn_ballot_w64(hl), mr = __builtin_amdgcn_ballot_w64(hr);
+            const uint32_t lref = __float_as_uint(n3.x), rref = __float_as_uint(n3.y);
+            if (ml && mr) {
+                // both: enter the child that is nearer for most lanes first, keep the other on the stack
+                const unsigned long long lf = __builtin_amdgcn_ballot_w64(hl & (!hr | (lnear <= rnear)));
+                const bool left_first = 2 * __builtin_popcountll(lf) >= __builtin_popcountll(ml | mr);
+                stack[sp] = left_first ? rref : lref;  // every active lane stores the same word
+                ++sp;
+                ref = left_first ? lref : rref;
+                continue;
+            }
+            if (ml | mr) {
+                ref = ml ? lref : rref;
+                continue;
+            }
+        }
+        if (sp == 0) break;
+        --sp;
+        ref = __builtin_amdgcn_readfirstlane(stack[sp]);
+    }
     return h;
 }
 
@@ -286,6 +351,7 @@ __device__ __forceinline__ unsigned __reduce_max_trips(unsigned v) {
 
 template <int KIND>  // PtProgramKind
 __global__ __launch_bounds__(256) void pt_render_kernel(const PtKernelParams p) {
+    __shared__ uint32_t s_stack[KIND == 2 ? 4 : 1][KIND == 2 ? PT_BVH_STACK : 1];
     int x, y;
     const int tile = tile_of_block(p);
     const bool in_window = pixel_of_lane(p, tile, x, y);
@@ -317,7 +383,8 @@ __global__ __launch_bounds__(256) void pt_render_kernel(const PtKernelParams p) 
         Hit h;
         v3 N = V(0.f, 0.f, 0.f);
         if (KIND == 0) h = intersect_world(p.spheres, ro, rd, N);
-        else h = intersect_mesh(p.tris, p.num_triangles, rd);
+        else if (KIND == 1) h = intersect_mesh(p.tris, p.num_triangles, rd);
+        else h = intersect_bvh(p, rd, s_stack[threadIdx.x >> 6]);
         ++rays;
         ++trips;
         const bool hit = h.id >= 0;
@@ -362,15 +429,19 @@ __global__ __launch_bounds__(256) void pt_render_kernel(const PtKernelParams p) 
 
 template <int KIND>
 __global__ __launch_bounds__(256) void pt_primary_kernel(const PtKernelParams p) {
+    __shared__ uint32_t s_stack[KIND == 2 ? 4 : 1][KIND == 2 ? PT_BVH_STACK : 1];
     int x, y;
-    if (!pixel_of_lane(p, (int)blockIdx.x, x, y)) return;
+    const bool in_window = pixel_of_lane(p, (int)blockIdx.x, x, y);
+    if (KIND != 2 && !in_window) return;  // the BVH walk is per wave: every lane stays for the ballots
     const size_t pix = (size_t)y * p.width + x;
     const v3 ro = V(p.ro[0], p.ro[1], p.ro[2]);
     const v3 rd = primary_direction(p, (float)x + 0.5f, (float)y + 0.5f);
     Hit h;
     v3 N;
     if (KIND == 0) h = intersect_world(p.spheres, ro, rd, N);
-    else h = intersect_mesh(p.tris, p.num_triangles, rd);
+    else if (KIND == 1) h = intersect_mesh(p.tris, p.num_triangles, rd);
+    else h = intersect_bvh(p, rd, s_stack[threadIdx.x >> 6]);
+    if (!in_window) return;
     if (p.out_ids) p.out_ids[pix] = h.id;
     if (p.out_t) p.out_t[pix] = h.t;
 }
@@ -469,13 +540,15 @@ hipError_t pt_launch_schedule_tiles(uint32_t* tile_cost, uint32_t* tile_order, i
 hipError_t pt_launch_render(const PtKernelParams& p, int program_kind, hipStream_t stream) {
     if (p.win_w <= 0 || p.win_h <= 0 || p.num_samples <= 0) return hipSuccess;
     if (program_kind == 0) hipLaunchKernelGGL(pt_render_kernel<0>, dim3(window_tiles(p)), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL(pt_render_kernel<1>, dim3(window_tiles(p)), dim3(256), 0, stream, p);
+    else if (!p.bvh_nodes) hipLaunchKernelGGL(pt_render_kernel<1>, dim3(window_tiles(p)), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(pt_render_kernel<2>, dim3(window_tiles(p)), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 
 hipError_t pt_launch_primary(const PtKernelParams& p, int program_kind, hipStream_t stream) {
     if (p.win_w <= 0 || p.win_h <= 0) return hipSuccess;
     if (program_kind == 0) hipLaunchKernelGGL(pt_primary_kernel<0>, dim3(window_tiles(p)), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL(pt_primary_kernel<1>, dim3(window_tiles(p)), dim3(256), 0, stream, p);
+    else if (!p.bvh_nodes) hipLaunchKernelGGL(pt_primary_kernel<1>, dim3(window_tiles(p)), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(pt_primary_kernel<2>, dim3(window_tiles(p)), dim3(256), 0, stream, p);
     return hipGetLastError();
 }

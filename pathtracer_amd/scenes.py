@@ -25,8 +25,45 @@ WORKLOADS = {
 }
 
 
+def _lcg_uniform(count, seed=20260101):
+    """Deterministic uniform [0,1) stream: 32-bit LCG (Numerical Recipes constants), top 24 bits."""
+    out = np.empty(count, np.float64)
+    state = seed & 0xFFFFFFFF
+    for i in range(count):
+        state = (1664525 * state + 1013904223) & 0xFFFFFFFF
+        out[i] = (state >> 8) / float(1 << 24)
+    return out
+
+
+def instanced_mesh(vertices, indices, instances=254, columns=16, spacing=2.8, unit=30.0, seed=20260101):
+    """Synthetic large scene: `instances` copies of a mesh on a jittered columns-wide grid facing the camera, each
+    with its own yaw, jitter and depth from a fixed LCG seed, everything scaled to Cornell-like units so that the
+    shader's absolute `det >= 1e-4` cull keeps the small triangles. Returns (vertices6, indices)."""
+    v = np.asarray(vertices, np.float32).reshape(-1, 6)[:, :3].astype(np.float64)
+    idx = np.asarray(indices, np.uint32).reshape(-1, 3)
+    rnd = _lcg_uniform(instances * 4, seed).reshape(instances, 4)
+    rows = (instances + columns - 1) // columns
+    out_v = np.zeros((instances * len(v), 6), np.float32)
+    out_i = np.zeros((instances * len(idx), 3), np.uint32)
+    for k in range(instances):
+        cx = (k % columns - (columns - 1) / 2.0) * spacing + (rnd[k, 0] - 0.5) * 0.8
+        cy = (k // columns - (rows - 1) / 2.0) * spacing + (rnd[k, 1] - 0.5) * 0.8
+        cz = (rnd[k, 2] - 0.5) * 6.0
+        yaw = (rnd[k, 3] - 0.5) * 1.0
+        c, s_ = np.cos(yaw), np.sin(yaw)
+        x = v[:, 0] * c + v[:, 2] * s_
+        z = -v[:, 0] * s_ + v[:, 2] * c
+        p = np.stack([x + cx, v[:, 1] + cy, z + cz], 1) * unit
+        out_v[k * len(v):(k + 1) * len(v), :3] = p.astype(np.float32)
+        out_i[k * len(idx):(k + 1) * len(idx)] = idx + np.uint32(k * len(v))
+    return out_v, out_i
+
+
 class SceneData:
     def __init__(self, name, width=None, height=None):
+        if name == "instanced":
+            self._init_instanced(width, height)
+            return
         obj, view, program, w0, h0 = WORKLOADS[name]
         self.name, self.program = name, program
         self.width, self.height = width or w0, height or h0
@@ -39,7 +76,22 @@ class SceneData:
         self.spheres, self.materials = host_api.reference_spheres()
         self.num_triangles = len(self.indices)
 
-    def upload(self, tracer, depth=10):
+    def _init_instanced(self, width, height):
+        """~1M triangles: 254 copies of suzanne.obj (3936 triangles each = 999,744), geometric normals, camera on the
+        grid's axis far enough to see all of it."""
+        self.name, self.program = "instanced", capi.PROGRAM_MESH
+        self.width, self.height = width or 3840, height or 2160
+        o = host_api.ObjFile(os.path.join(ASSETS, "suzanne.obj"), ASSETS + "/")
+        base = o.mesh_untranslated
+        unit = 30.0
+        self.vertices, self.indices = instanced_mesh(base["vertices"], base["indices"], unit=unit)
+        self.material_ids = np.zeros(len(self.indices), np.int32)
+        self.normal_mode = capi.NORMALS_GEOMETRIC
+        self.camera = host_api.camera(60.0, self.width, self.height, (0.0, 0.0, -44.0 * unit), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0))
+        self.spheres, self.materials = host_api.reference_spheres()
+        self.num_triangles = len(self.indices)
+
+    def upload(self, tracer, depth=10, accel=True):
         """Scene upload + program + uniforms on a Tracer; the target is the caller's business."""
         prog = tracer.program_create(self.program)
         tracer.use_program(prog)
@@ -48,4 +100,6 @@ class SceneData:
         tracer.upload_mesh(self.vertices, self.indices)
         tracer.set_normal_mode(self.normal_mode)
         tracer.set_uniforms(self.camera, self.num_triangles, depth)
+        if accel:
+            tracer.build_accel()   # used by dispatches when the mesh is large enough (PT_ACCEL_AUTO)
         return prog

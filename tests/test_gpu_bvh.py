@@ -1,0 +1,127 @@
+"""The device-built LBVH must not change a single result: closest-hit ids, distances and radiance through the BVH
+equal the all-triangles loop (the shader's own formulation) bit for bit -- including exact ties, which the shader's
+ascending loop with a strict '<' gives to the lowest triangle index."""
+import numpy as np
+import pytest
+
+import pt_oracle as po
+from helpers import load_case, n_bit_mismatch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tracer():
+    from pathtracer_amd import Tracer
+    t = Tracer(0)
+    yield t
+    t.close()
+
+
+def both_modes(t, verts, idx, cam, W, H, normal_mode, spp=3, window=None):
+    from pathtracer_amd import capi
+    sph, mat = po.reference_spheres_and_materials()
+    prog = t.program_create(capi.PROGRAM_MESH)
+    t.use_program(prog)
+    t.upload_spheres(sph)
+    t.upload_mesh(verts, idx)
+    t.set_normal_mode(normal_mode)
+    t.set_accum_mode(capi.ACCUM_MEAN)
+    t.target_create(W, H)
+    if window:
+        t.set_window(*window)
+    t.set_uniforms(cam, len(idx), 10)
+    t.build_accel()
+    res = {}
+    for name, mode in (("brute", capi.ACCEL_BRUTE), ("bvh", capi.ACCEL_BVH)):
+        t.set_accel_mode(mode)
+        t.target_clear()
+        t.reset_stats()
+        ids, ts = t.readback_primary()
+        if spp:
+            t.dispatch(1, spp, 1)
+            t.finish()
+        res[name] = (ids, ts, t.readback(), t.stats()["rays"])
+    t.set_accel_mode(capi.ACCEL_AUTO)
+    t.program_destroy(prog)
+    return res
+
+
+def assert_same(res):
+    b, a = res["brute"], res["bvh"]
+    assert np.array_equal(a[0], b[0]), f"{(a[0] != b[0]).sum()} primary ids differ"
+    assert n_bit_mismatch(a[1], b[1]) == 0
+    assert n_bit_mismatch(a[2], b[2]) == 0
+    assert a[3] == b[3]
+
+
+@pytest.mark.parametrize("name", ["monkey_mesh_128", "cornell_geo_128", "suzanne_geo_96"])
+def test_bvh_equals_brute_force_on_golden_scenes(tracer, name):
+    fx = load_case(name)
+    W, H = int(fx["width"]), int(fx["height"])
+    res = both_modes(tracer, fx["vertices"], fx["indices"], fx["camera"], W, H, int(fx["normal_mode"]), spp=2)
+    assert_same(res)
+    # and both equal what the reference shader produced
+    assert np.array_equal(res["bvh"][0], fx["lp_id"])
+    assert n_bit_mismatch(res["bvh"][2][..., :3], fx["lp_rgb_2"]) == 0
+
+
+def test_exact_ties_go_to_the_lowest_index(tracer):
+    """Every triangle twice (ids k and k+N share geometry), in shuffled order: each hit is an exact tie."""
+    fx = load_case("monkey_mesh_128")
+    idx = fx["indices"]
+    rng = np.random.default_rng(3)
+    doubled = np.concatenate([idx, idx])[rng.permutation(2 * len(idx))]
+    res = both_modes(tracer, fx["vertices"], doubled, fx["camera"], 128, 128, 0, spp=2)
+    assert_same(res)
+    ids = res["bvh"][0]
+    hit = ids >= 0
+    assert hit.sum() > 3000
+    # the winner is the first occurrence of that triangle in the index list
+    first_pos = {}
+    for pos, tri in enumerate(map(tuple, doubled)):
+        first_pos.setdefault(tri, pos)
+    assert all(first_pos[tuple(doubled[i])] == i for i in np.unique(ids[hit]))
+    scene = po.Scene(fx["vertices"], doubled, fx["spheres"], fx["materials"])
+    u = po.uniforms(fx["camera"], 128, 128, len(doubled), 10, 1, 0)
+    oids, _, _ = po.primary(scene, u, threads=8)
+    assert np.array_equal(ids, oids)
+
+
+def test_random_soup_and_degenerate_layouts(tracer):
+    rng = np.random.default_rng(11)
+    W, H = 200, 120
+    cam = po.camera(55.0, W, H, (0.2, 0.1, -2.0), (0.0, 0.0, 5.0), (0.0, 1.0, 0.0))
+    # (a) random soup, (b) all triangles in one plane sharing edges (grid), (c) many coincident centroids
+    nt = 5000
+    base = rng.uniform(-3, 3, (nt, 1, 3)) + np.array([0, 0, 7.0])
+    soup = (base + rng.uniform(-0.5, 0.5, (nt, 3, 3))).astype(np.float32)
+    g = 40
+    xs, ys = np.meshgrid(np.linspace(-3, 3, g + 1), np.linspace(-2, 2, g + 1))
+    P = np.stack([xs, ys, np.full_like(xs, 6.0)], -1).astype(np.float32)
+    quads = []
+    for j in range(g):
+        for i in range(g):
+            a, b, c, d = P[j, i], P[j, i + 1], P[j + 1, i + 1], P[j + 1, i]
+            quads += [[a, c, b], [a, d, c]]
+    grid = np.array(quads, np.float32)
+    fan = np.array([[[0, 0, 5.0], [np.cos(t + 0.3) * 2, np.sin(t + 0.3) * 2, 5.0 + 0.01 * k], [np.cos(t) * 2, np.sin(t) * 2, 5.0 + 0.01 * k]]
+                    for k, t in enumerate(np.linspace(0, 6.28, 300))], np.float32)
+    for tris in (soup, grid, fan):
+        verts = np.concatenate([tris.reshape(-1, 3), np.zeros((tris.shape[0] * 3, 3), np.float32)], 1)
+        idx = np.arange(len(verts), dtype=np.uint32).reshape(-1, 3)
+        res = both_modes(tracer, verts, idx, cam, W, H, 1, spp=2)
+        assert_same(res)
+        assert (res["bvh"][0] >= 0).sum() > 1000
+
+
+def test_million_triangle_scene_crops(tracer):
+    """~1M triangles (254 suzanne instances): BVH vs all-triangles loop on crops of the 4K frame."""
+    from pathtracer_amd.scenes import SceneData
+    sc = SceneData("instanced")
+    assert 990_000 < sc.num_triangles < 1_010_000
+    for window in [(1900, 1060, 64, 64), (1235, 520, 64, 48), (2430, 1470, 48, 64)]:
+        res = both_modes(tracer, sc.vertices, sc.indices, sc.camera, sc.width, sc.height, sc.normal_mode, spp=1, window=window)
+        assert_same(res)
+        x0, y0, w, h = window
+        assert (res["bvh"][0][y0:y0 + h, x0:x0 + w] >= 0).sum() > 100

@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--lib", default=None)
+    ap.add_argument("--accel", default="auto", choices=["auto", "brute", "bvh"])
     args = ap.parse_args()
     from pathtracer_amd import Tracer
     from pathtracer_amd.scenes import SceneData
@@ -24,6 +25,16 @@ def main():
     t = Tracer(0, args.lib)
     scene.upload(t)
     t.target_create(scene.width, scene.height)
+    if args.accel == "bvh":
+        import time
+        t0 = time.perf_counter()
+        t.build_accel()
+        t.finish()
+        build_s = time.perf_counter() - t0
+        t.set_accel_mode(2)
+    else:
+        build_s = 0.0
+        t.set_accel_mode(1 if args.accel == "brute" else 0)
     t.enable_timing(True)
     t.dispatch(1, 1, 1)
     t.finish()
@@ -37,7 +48,7 @@ def main():
     st = t.stats()
     ms = st["total_dispatch_ms"] / st["dispatches"]
     print(json.dumps({"workload": args.workload, "size": [scene.width, scene.height], "spp": args.spp, "triangles": scene.num_triangles,
-                      "kernel_ms": ms, "per_rep_ms": per_rep, "Grays_per_s": st["rays"] / st["dispatches"] / ms * 1e-6,
+                      "accel": args.accel, "bvh_build_s": round(build_s, 4), "kernel_ms": ms, "per_rep_ms": per_rep, "Grays_per_s": st["rays"] / st["dispatches"] / ms * 1e-6,
                       "rays_per_sample": st["rays"] / st["samples"], "lane_utilisation": st["rays"] / st["lane_slots"]}))
     t.close()
 
