@@ -86,6 +86,8 @@ typedef struct PtStats {
     uint64_t samples;          /* pixel-samples (shader invocations) */
     uint64_t lane_slots;       /* 64 x the loop trips of every wave: rays / lane_slots is the fraction of SIMD lanes
                                   that did useful work (paths in one wave end at different times) */
+    uint64_t bvh_node_fetches; /* LBVH traversal: 64-byte node records fetched, counted once per WAVE (the walk is per wave) */
+    uint64_t bvh_triangle_fetches; /* LBVH traversal: 64-byte triangle records (+4-byte id) fetched, once per wave */
     uint32_t dispatches;       /* render-kernel launches */
     float last_dispatch_ms;    /* duration of the most recent render kernel; 0 unless timing is enabled */
     double total_dispatch_ms;  /* sum over dispatches since the last reset; 0 unless timing is enabled */

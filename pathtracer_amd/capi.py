@@ -26,7 +26,8 @@ class PtUniforms(C.Structure):
 
 
 class PtStats(C.Structure):
-    _fields_ = [("rays", C.c_uint64), ("samples", C.c_uint64), ("lane_slots", C.c_uint64), ("dispatches", C.c_uint32),
+    _fields_ = [("rays", C.c_uint64), ("samples", C.c_uint64), ("lane_slots", C.c_uint64), ("bvh_node_fetches", C.c_uint64),
+                ("bvh_triangle_fetches", C.c_uint64), ("dispatches", C.c_uint32),
                 ("last_dispatch_ms", C.c_float), ("total_dispatch_ms", C.c_double)]
 
 
@@ -222,7 +223,8 @@ class Tracer:
     def stats(self):
         s = PtStats()
         check(self._lib.pt_get_stats(self._ctx, C.byref(s)), self._lib)
-        return {"rays": s.rays, "samples": s.samples, "lane_slots": s.lane_slots, "dispatches": s.dispatches,
+        return {"rays": s.rays, "samples": s.samples, "lane_slots": s.lane_slots, "bvh_node_fetches": s.bvh_node_fetches,
+                "bvh_triangle_fetches": s.bvh_triangle_fetches, "dispatches": s.dispatches,
                 "last_dispatch_ms": s.last_dispatch_ms, "total_dispatch_ms": s.total_dispatch_ms}
 
     def reset_stats(self):

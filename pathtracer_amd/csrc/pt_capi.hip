@@ -268,8 +268,8 @@ PtStatus pt_create(int32_t device, PtContext** out_ctx) {
     PT_REQUIRE(ctx != nullptr, PT_ERR_HIP, "out of host memory");
     ctx->device = device;
     hipError_t err = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
-    if (err == hipSuccess) err = hipMalloc(&ctx->d_counters, 2 * sizeof(unsigned long long));
-    if (err == hipSuccess) err = hipMemsetAsync(ctx->d_counters, 0, 2 * sizeof(unsigned long long), ctx->own_stream);
+    if (err == hipSuccess) err = hipMalloc(&ctx->d_counters, 4 * sizeof(unsigned long long));
+    if (err == hipSuccess) err = hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(unsigned long long), ctx->own_stream);
     if (err == hipSuccess) err = hipStreamSynchronize(ctx->own_stream);
     if (err == hipSuccess) err = hipMalloc(&ctx->d_spheres, 40 * sizeof(float));
     if (err == hipSuccess) err = hipEventCreate(&ctx->ev_start);
@@ -654,12 +654,14 @@ PtStatus pt_get_stats(PtContext* ctx, PtStats* out) {
     PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
     s = collect_timing(ctx);
     if (s != PT_OK) return s;
-    unsigned long long c[2] = {0, 0};
+    unsigned long long c[4] = {0, 0, 0, 0};
     PT_HIP_TRY(hipMemcpyAsync(c, ctx->d_counters, sizeof c, hipMemcpyDeviceToHost, ctx->stream));
     PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
     out->rays = c[0];
     out->samples = ctx->samples;
     out->lane_slots = c[1];
+    out->bvh_node_fetches = c[2];
+    out->bvh_triangle_fetches = c[3];
     out->dispatches = ctx->dispatches;
     out->last_dispatch_ms = ctx->last_ms;
     out->total_dispatch_ms = ctx->total_ms;
@@ -672,7 +674,7 @@ PtStatus pt_reset_stats(PtContext* ctx) {
     PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
     s = collect_timing(ctx);
     if (s != PT_OK) return s;
-    PT_HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    PT_HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(unsigned long long), ctx->stream));
     PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->samples = 0;
     ctx->dispatches = 0;

@@ -186,7 +186,8 @@ __device__ __forceinline__ Hit intersect_mesh(const float* __restrict__ tris, in
 // their paths through the tree is short. A lane's box test passes when its ray can reach the padded box no farther than
 // its current hit (equal distance included, so a lower-id triangle at the same distance is still found); leaves run
 // the exact triangle test with the explicit lowest-id rule. The result equals the all-triangles loop bit for bit.
-__device__ __forceinline__ Hit intersect_bvh(const PtKernelParams& p, v3 rd, uint32_t* __restrict__ stack) {
+__device__ __forceinline__ Hit intersect_bvh(const PtKernelParams& p, v3 rd, uint32_t* __restrict__ stack, unsigned& node_visits,
+                                             unsigned& tri_tests) {
     Hit h;
     h.t = 1.0e38f; h.id = -1; h.u = 0.f; h.v = 0.f; h.ood = 0.f;
     // Reciprocal direction for the slab tests only (culling arithmetic is not part of the reference's numerics; it
@@ -204,7 +205,9 @@ __device__ __forceinline__ Hit intersect_bvh(const PtKernelParams& p, v3 rd, uin
         if (ref & 0x80000000u) {
             const int first = (int)((ref & 0x7fffffffu) >> 3), count = (int)(ref & 7u) + 1;
             for (int k = 0; k < count; ++k) test_triangle<true>(load_rec(recs, first + k), p.bvh_ids[first + k], rd, h);
+            tri_tests += (unsigned)count;
         } else {
+            ++node_visits;
             const float4 n0 = nodes[4 * (size_t)ref], n1 = nodes[4 * (size_t)ref + 1], n2 = nodes[4 * (size_t)ref + 2],
                          n3 = nodes[4 * (size_t)ref + 3];
             const float limit = h.t * 1.0001f;
@@ -371,6 +374,7 @@ __global__ __launch_bounds__(256) void pt_render_kernel(const PtKernelParams p) 
     int sample = p.first_sample;
     unsigned rays = 0;
     unsigned trips = 0;  // loop trips of this wave: trips x 64 lane slots were spent for `rays` useful ones
+    unsigned node_visits = 0, tri_tests = 0;  // per WAVE (the BVH walk is wave-uniform): records fetched
 
     // path state
     v3 rd = rd0;
@@ -384,7 +388,7 @@ __global__ __launch_bounds__(256) void pt_render_kernel(const PtKernelParams p) 
         v3 N = V(0.f, 0.f, 0.f);
         if (KIND == 0) h = intersect_world(p.spheres, ro, rd, N);
         else if (KIND == 1) h = intersect_mesh(p.tris, p.num_triangles, rd);
-        else h = intersect_bvh(p, rd, s_stack[threadIdx.x >> 6]);
+        else h = intersect_bvh(p, rd, s_stack[threadIdx.x >> 6], node_visits, tri_tests);
         ++rays;
         ++trips;
         const bool hit = h.id >= 0;
@@ -424,6 +428,10 @@ __global__ __launch_bounds__(256) void pt_render_kernel(const PtKernelParams p) 
         atomicAdd(&p.counters[0], wave_rays);
         atomicAdd(&p.counters[1], (unsigned long long)wave_trips * 64ull);
         if (p.tile_cost) atomicAdd(&p.tile_cost[tile], wave_trips);
+        if (KIND == 2) {
+            atomicAdd(&p.counters[2], (unsigned long long)__builtin_amdgcn_readfirstlane(node_visits));
+            atomicAdd(&p.counters[3], (unsigned long long)__builtin_amdgcn_readfirstlane(tri_tests));
+        }
     }
 }
 
@@ -440,7 +448,8 @@ __global__ __launch_bounds__(256) void pt_primary_kernel(const PtKernelParams p)
     v3 N;
     if (KIND == 0) h = intersect_world(p.spheres, ro, rd, N);
     else if (KIND == 1) h = intersect_mesh(p.tris, p.num_triangles, rd);
-    else h = intersect_bvh(p, rd, s_stack[threadIdx.x >> 6]);
+    unsigned nv = 0, tt = 0;
+    if (KIND == 2) h = intersect_bvh(p, rd, s_stack[threadIdx.x >> 6], nv, tt);
     if (!in_window) return;
     if (p.out_ids) p.out_ids[pix] = h.id;
     if (p.out_t) p.out_t[pix] = h.t;
