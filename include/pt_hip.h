@@ -175,6 +175,10 @@ PtStatus pt_finish(PtContext* ctx);
 
 /* Copies the current image (the one the last pass wrote) to host: width*height*4 floats, row 0 = bottom. */
 PtStatus pt_readback_rgba32f(PtContext* ctx, float* dst);
+/* Replaces the present quad (PathTracer.cpp:1473-1491 with data/shaders/copy.fs:12-20): display colour
+ * pow(rgb, 0.454545) of the current image, converted to 8 bits per channel as an RGBA8 render target does, copied to
+ * host as width*height RGBA bytes, row 0 = bottom. The reference draws this into its window; a host shows or saves it. */
+PtStatus pt_present_rgba8(PtContext* ctx, uint8_t* dst);
 /* Device address of the current image (for hosts that consume it on the device). */
 PtStatus pt_current_image(PtContext* ctx, void** out_device_ptr);
 /* Traces primary rays only and copies per-pixel closest-hit ids (int32; -1 = miss; sphere id for

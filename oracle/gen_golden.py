@@ -108,7 +108,10 @@ def render_case(name, scene, cam, W, H, variant, normal_mode, spp_list, crop=Non
     job = dict(base, num_samples=max(spp_list), dump_after=list(spp_list))
     if rad_edit:
         job["edits"] = f"{EDITS}/{rad_edit}.txt"
+    if not crop:
+        job["present_out"] = f"{tmp}/present.u8"   # the reference's copy.fs pass over the final image
     _, dumps, info = harness(job, tmp)
+    present = None if crop else np.fromfile(f"{tmp}/present.u8", np.uint8).reshape(H, W, 4)
     shutil.rmtree(tmp)
 
     fx = {"width": W, "height": H, "depth": depth, "variant": variant, "normal_mode": normal_mode,
@@ -120,6 +123,8 @@ def render_case(name, scene, cam, W, H, variant, normal_mode, spp_list, crop=Non
     for k, img in dumps.items():
         assert np.all(img[..., 3] == 1.0)
         fx[f"lp_rgb_{k}"] = img[..., :3].copy()
+    if present is not None:
+        fx["lp_present_rgba8"] = present
 
     # ---- immediate check of the restatement against what llvmpipe produced
     x0, y0, w, h = fx["crop"]
@@ -141,6 +146,8 @@ def render_case(name, scene, cam, W, H, variant, normal_mode, spp_list, crop=Non
         ref = fx[f"lp_rgb_{k}"]
         rep[f"rgb_{k}_bit_mismatch"] = int((mine.view(np.uint32) != ref.view(np.uint32)).sum())
         rep[f"rgb_{k}_max_abs"] = float(np.abs(mine - ref).max())
+    if present is not None:
+        rep["present_byte_mismatch"] = int((po.present(rgba) != present).sum())
     rep["lp_pass_ms_median"] = float(np.median(info["pass_ms"]))
     print(json.dumps(rep))
     return fx, rep

@@ -180,6 +180,7 @@ struct Job {
     int num_triangles = 0;
     int tex_width = 1024;               // reference: 1024 (PathTracer.cpp:1274,1287)
     std::string spheres, materials, vertices, indices, init_accum, out;
+    std::string present_out;            // if set: also run the reference's present pass (copy.fs) into an RGBA8 target
     std::vector<int> dump_after;        // also dump out.<k>.f32 after these 1-based pass counts
     int crop[4] = {0, 0, 0, 0};         // x0 y0 w h; w==0 means full frame
     bool print_source = false;
@@ -223,6 +224,7 @@ static Job parse_job(const char* path) {
         else if (k == "indices") ss >> j.indices;
         else if (k == "init_accum") ss >> j.init_accum;
         else if (k == "out") ss >> j.out;
+        else if (k == "present_out") ss >> j.present_out;
         else if (k == "dump_after") { int v; while (ss >> v) j.dump_after.push_back(v); }
         else if (k == "crop") { for (int i = 0; i < 4; i++) ss >> j.crop[i]; }
         else if (k == "print_source") j.print_source = true;
@@ -489,6 +491,48 @@ int main(int argc, char** argv) {
     if (!job.out.empty()) {
         read_back(cur ^ 1);  // the target written by the last pass
         write_f32(job.out, out);
+    }
+
+    // Present pass as the reference host issues it (PathTracer.cpp:1473-1491): copy.fs over a full-screen quad with the
+    // last result bound as u_Texture. The reference draws it into the window's back buffer; here the target is an
+    // RGBA8 texture of the frame's size, read back as bytes.
+    if (!job.present_out.empty()) {
+        std::vector<char> cfs_raw = read_file(job.shader_dir + "/copy.fs");
+        GLuint cfs = compile(GL_FRAGMENT_SHADER, std::string(verstr) + std::string(cfs_raw.begin(), cfs_raw.end()), "copy.fs");
+        GLuint cprog = glCreateProgram();
+        glAttachShader(cprog, vs);
+        glAttachShader(cprog, cfs);
+        glLinkProgram(cprog);
+        GLint ok = 0;
+        glGetProgramiv(cprog, GL_LINK_STATUS, &ok);
+        if (!ok) die("copy program failed to link");
+        GLuint ptex, pfbo;
+        glGenTextures(1, &ptex);
+        glBindTexture(GL_TEXTURE_2D, ptex);
+        glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MAG_FILTER, GL_NEAREST);
+        glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MIN_FILTER, GL_NEAREST);
+        glTexImage2D(GL_TEXTURE_2D, 0, GL_RGBA8, W, H, 0, GL_RGBA, GL_UNSIGNED_BYTE, nullptr);
+        glGenFramebuffers(1, &pfbo);
+        glBindFramebuffer(GL_FRAMEBUFFER, pfbo);
+        glFramebufferTexture2D(GL_FRAMEBUFFER, GL_COLOR_ATTACHMENT0, GL_TEXTURE_2D, ptex, 0);
+        if (glCheckFramebufferStatus(GL_FRAMEBUFFER) != GL_FRAMEBUFFER_COMPLETE) die("present FBO incomplete");
+        glDisable(GL_SCISSOR_TEST);
+        glUseProgram(cprog);
+        glActiveTexture(GL_TEXTURE0);
+        glBindTexture(GL_TEXTURE_2D, tex[cur ^ 1]);
+        glUniform1i(glGetUniformLocation(cprog, "u_Texture"), 0);
+        glUniform1f(glGetUniformLocation(cprog, "u_InvNumSamples"), (float)(job.first_sample + job.num_samples - 1));
+        glBindVertexArray(vao);
+        glDrawArrays(GL_TRIANGLE_STRIP, 0, 4);
+        glFinish();
+        std::vector<unsigned char> bytes((size_t)W * H * 4);
+        glReadBuffer(GL_COLOR_ATTACHMENT0);
+        glReadPixels(0, 0, W, H, GL_RGBA, GL_UNSIGNED_BYTE, bytes.data());
+        GLCHECK("present");
+        FILE* pf = fopen(job.present_out.c_str(), "wb");
+        if (!pf) die("cannot write present_out");
+        fwrite(bytes.data(), 1, bytes.size(), pf);
+        fclose(pf);
     }
 
     // one JSON line on stdout

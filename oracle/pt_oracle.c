@@ -413,6 +413,22 @@ PTO_API uint64_t pto_render_sum(const PtoScene* sc, const PtoUniforms* u, int fi
     return rays;
 }
 
+/* Present pass, /root/reference/data/shaders/copy.fs:12-20 as llvmpipe renders it into an 8-bit target:
+ * pow(rgb, 0.454545) with the polynomial pow above, then float -> UNORM8 = clamp to [0,1], times 255, round to nearest
+ * even; alpha 1 -> 255. (The unused u_InvNumSamples uniform has no effect, copy.fs:8,16.) */
+PTO_API void pto_present(const float* rgba, int num_pixels, uint8_t* out_rgba8) {
+    FpGuard g = fp_enter();
+    for (int i = 0; i < num_pixels; i++) {
+        for (int c = 0; c < 3; c++) {
+            float v = lp_pow(rgba[4 * i + c], 0.454545f);
+            v = fminf(fmaxf(v, 0.0f), 1.0f);
+            out_rgba8[4 * i + c] = (uint8_t)nearbyintf(v * 255.0f);
+        }
+        out_rgba8[4 * i + 3] = 255;
+    }
+    fp_leave(g);
+}
+
 /* n successive rand01() draws (fs:29-42) at pixel (px,py) in pass `samples`. */
 PTO_API void pto_rng_stream(int px, int py, float samples, int n, float* out) {
     FpGuard g = fp_enter();

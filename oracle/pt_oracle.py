@@ -55,6 +55,8 @@ def lib():
         L.pto_rng_stream.argtypes = [C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]
         L.pto_camera.restype = None
         L.pto_camera.argtypes = [C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.pto_present.restype = None
+        L.pto_present.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.pto_lp_math.restype = None
         L.pto_lp_math.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
@@ -156,6 +158,14 @@ def primary(scene, u, window=None, threads=1):
     _parallel(lambda ya, hh: L.pto_primary(C.byref(sc), C.byref(u), ids.ctypes.data, ts.ctypes.data, rds.ctypes.data,
                                            x0, ya, w, hh), _row_chunks(y0, h, threads))
     return ids, ts, rds
+
+
+def present(rgba):
+    """copy.fs on an 8-bit target: [H, W, 4] float32 -> [H, W, 4] uint8."""
+    rgba = np.ascontiguousarray(rgba, np.float32)
+    out = np.zeros(rgba.shape, np.uint8)
+    lib().pto_present(rgba.ctypes.data, rgba.size // 4, out.ctypes.data)
+    return out
 
 
 def rng_stream(px, py, samples, n):

@@ -63,6 +63,7 @@ SIGNATURES = {
     "pt_dispatch": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "pt_finish": (C.c_int, [C.c_void_p]),
     "pt_readback_rgba32f": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pt_present_rgba8": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pt_current_image": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "pt_readback_primary": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "pt_enable_timing": (C.c_int, [C.c_void_p, C.c_int32]),
@@ -204,6 +205,11 @@ class Tracer:
     def readback(self):
         out = np.empty((self.height, self.width, 4), np.float32)
         check(self._lib.pt_readback_rgba32f(self._ctx, out.ctypes.data), self._lib)
+        return out
+
+    def present(self):
+        out = np.empty((self.height, self.width, 4), np.uint8)
+        check(self._lib.pt_present_rgba8(self._ctx, out.ctypes.data), self._lib)
         return out
 
     def current_image_ptr(self):

@@ -611,6 +611,19 @@ PtStatus pt_readback_rgba32f(PtContext* ctx, float* dst) {
     return PT_OK;
 }
 
+PtStatus pt_present_rgba8(PtContext* ctx, uint8_t* dst) {
+    PtStatus s = bind(ctx);
+    if (s != PT_OK) return s;
+    PT_REQUIRE(dst != nullptr, PT_ERR_INVALID_ARGUMENT, "dst is null");
+    PT_REQUIRE(ctx->d_image[0] != nullptr, PT_ERR_STATE, "no accumulation target");
+    const size_t n = (size_t)ctx->width * ctx->height;
+    // the primary-id buffer (4 bytes per pixel) doubles as the staging area of the 8-bit image
+    PT_HIP_TRY(pt_launch_present(ctx->d_image[ctx->current ^ 1], n, reinterpret_cast<uint32_t*>(ctx->d_ids), ctx->stream));
+    PT_HIP_TRY(hipMemcpyAsync(dst, ctx->d_ids, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
 PtStatus pt_current_image(PtContext* ctx, void** out_device_ptr) {
     PT_REQUIRE(ctx != nullptr && out_device_ptr != nullptr, PT_ERR_INVALID_ARGUMENT, "null argument");
     PT_REQUIRE(ctx->d_image[0] != nullptr, PT_ERR_STATE, "no accumulation target");

@@ -86,6 +86,7 @@ hipError_t pt_launch_prepare_triangles(const float* vertices, const uint32_t* in
                                        hipStream_t stream);
 hipError_t pt_launch_fill_rgba(float* img, size_t num_pixels, float r, float g, float b, float a, hipStream_t stream);
 hipError_t pt_launch_render(const PtKernelParams& p, int program_kind, hipStream_t stream);
+hipError_t pt_launch_present(const float* img, size_t num_pixels, uint32_t* out_rgba8, hipStream_t stream);
 // tile_order <- tiles sorted by descending tile_cost (bucketed); tile_cost <- 0
 hipError_t pt_launch_schedule_tiles(uint32_t* tile_cost, uint32_t* tile_order, int num_tiles, hipStream_t stream);
 hipError_t pt_launch_primary(const PtKernelParams& p, int program_kind, hipStream_t stream);

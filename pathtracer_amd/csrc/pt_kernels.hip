@@ -485,6 +485,23 @@ __global__ __launch_bounds__(256) void pt_prepare_triangles_kernel(const float* 
     gnormals[3 * (size_t)i] = g.x; gnormals[3 * (size_t)i + 1] = g.y; gnormals[3 * (size_t)i + 2] = g.z;
 }
 
+// Present pass: the reference's copy.fs (pow(rgb, 0.454545), copy.fs:18) followed by the float -> 8-bit conversion
+// of the render target it is drawn into: clamp to [0,1], x255, round to nearest even; alpha 1 -> 255.
+__global__ __launch_bounds__(256) void pt_present_kernel(const float4* __restrict__ img, size_t n, uint32_t* __restrict__ out) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float4 c = img[i];
+        const float ch[3] = {c.x, c.y, c.z};
+        uint32_t packed = 0xff000000u;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float v = clamp01(lp_pow(ch[k], 0.454545f));
+            packed |= (uint32_t)__builtin_rintf(v * 255.0f) << (8 * k);
+        }
+        out[i] = packed;
+    }
+}
+
 __global__ __launch_bounds__(256) void pt_fill_rgba_kernel(float4* img, size_t n, float4 value) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) img[i] = value;
@@ -537,6 +554,14 @@ hipError_t pt_launch_fill_rgba(float* img, size_t num_pixels, float r, float g, 
     const size_t blocks = (num_pixels + 255) / 256;
     hipLaunchKernelGGL(pt_fill_rgba_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream,
                        reinterpret_cast<float4*>(img), num_pixels, make_float4(r, g, b, a));
+    return hipGetLastError();
+}
+
+hipError_t pt_launch_present(const float* img, size_t num_pixels, uint32_t* out_rgba8, hipStream_t stream) {
+    if (num_pixels == 0) return hipSuccess;
+    const size_t blocks = (num_pixels + 255) / 256;
+    hipLaunchKernelGGL(pt_present_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, stream,
+                       reinterpret_cast<const float4*>(img), num_pixels, out_rgba8);
     return hipGetLastError();
 }
 

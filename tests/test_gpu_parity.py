@@ -55,6 +55,9 @@ def test_golden_case_bit_exact(tracer, name):
         img = t.readback()
         assert n_bit_mismatch(img[win][..., :3], fx[f"lp_rgb_{k}"]) == 0, f"radiance after {k} passes"
         assert np.all(img[win][..., 3] == 1.0)
+    if "lp_present_rgba8" in fx:
+        # the reference's copy.fs pass over the final image, as llvmpipe wrote it into an RGBA8 target
+        assert np.array_equal(t.present(), fx["lp_present_rgba8"]), "present pass bytes"
     t.program_destroy(prog)
 
 

@@ -58,6 +58,8 @@ def test_case_bit_exact(name):
         assert rays >= w * h * 1
         assert n_bit_mismatch(rgba[win][..., :3], fx[f"lp_rgb_{k}"]) == 0, f"{name}: radiance after {k} passes"
         assert np.all(rgba[win][..., 3] == 1.0)
+    if "lp_present_rgba8" in fx:
+        assert np.array_equal(po.present(rgba), fx["lp_present_rgba8"])
 
 
 def test_camera_reference_setup():
