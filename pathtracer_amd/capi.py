@@ -16,7 +16,7 @@ PT_ERR_INVALID_ARGUMENT, PT_ERR_HIP, PT_ERR_STATE, PT_ERR_NO_DEVICE, PT_ERR_UNSU
 PROGRAM_WORLD, PROGRAM_MESH = 0, 1
 NORMALS_VERTEX, NORMALS_GEOMETRIC = 0, 1
 ACCUM_MEAN, ACCUM_SUM = 0, 1
-ACCEL_AUTO, ACCEL_BRUTE, ACCEL_BVH = 0, 1, 2
+ACCEL_AUTO, ACCEL_BRUTE, ACCEL_BVH, ACCEL_CULL = 0, 1, 2, 3
 
 
 class PtUniforms(C.Structure):

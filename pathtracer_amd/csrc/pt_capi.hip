@@ -60,6 +60,7 @@ struct PtContext {
     float* d_tris = nullptr;        // SoA records, rebuilt when the mesh or the camera position changes
     float* d_vnormals = nullptr;
     float* d_gnormals = nullptr;
+    float* d_cull = nullptr;
     bool records_valid = false;
     float records_ro[3] = {0, 0, 0};
     // LBVH (optional)
@@ -156,7 +157,7 @@ void free_bvh(PtContext* ctx) {
 
 void free_mesh(PtContext* ctx) {
     free_bvh(ctx);
-    float** f[] = {&ctx->d_vertices, &ctx->d_tris, &ctx->d_vnormals, &ctx->d_gnormals};
+    float** f[] = {&ctx->d_vertices, &ctx->d_tris, &ctx->d_vnormals, &ctx->d_gnormals, &ctx->d_cull};
     for (float** q : f) {
         if (*q) (void)hipFree(*q);
         *q = nullptr;
@@ -172,7 +173,7 @@ PtStatus ensure_records(PtContext* ctx) {
     const float* ro = ctx->uniforms.camera_position;
     if (ctx->records_valid && memcmp(ro, ctx->records_ro, sizeof ctx->records_ro) == 0) return PT_OK;
     PT_HIP_TRY(pt_launch_prepare_triangles(ctx->d_vertices, ctx->d_indices, ctx->num_triangles, ro, ctx->d_tris,
-                                           ctx->d_vnormals, ctx->d_gnormals, ctx->stream));
+                                           ctx->d_vnormals, ctx->d_gnormals, ctx->d_cull, ctx->stream));
     // the BVH's boxes and leaf-order records are expressed relative to the ray origin too
     if (ctx->bvh_built) PT_HIP_TRY(pt_bvh_emit(ctx->bvh, ro, ctx->d_tris, ctx->stream));
     memcpy(ctx->records_ro, ro, sizeof ctx->records_ro);
@@ -213,7 +214,8 @@ PtStatus fill_params(PtContext* ctx, PtKernelParams* p, const Program** prog_out
         // the hierarchy covers the whole mesh, so it serves only when every uploaded triangle is traced
         // and in AUTO mode only when the mesh is big enough for the walk to beat the plain loop (36 triangles: the
         // loop is 15 % faster; 968: the BVH is 6x faster)
-        const bool use_bvh = ctx->bvh_built && ctx->accel_mode != PT_ACCEL_BRUTE && u.num_triangles == ctx->num_triangles &&
+        const bool use_bvh = ctx->bvh_built && ctx->accel_mode != PT_ACCEL_BRUTE && ctx->accel_mode != PT_ACCEL_CULL &&
+                             u.num_triangles == ctx->num_triangles &&
                              (ctx->accel_mode == PT_ACCEL_BVH || u.num_triangles > PT_BVH_AUTO_MIN_TRIANGLES);
         PT_REQUIRE(use_bvh || ctx->accel_mode != PT_ACCEL_BVH, PT_ERR_STATE, "the BVH covers all %d triangles but u_NumTriangles = %d",
                    ctx->num_triangles, u.num_triangles);
@@ -221,6 +223,8 @@ PtStatus fill_params(PtContext* ctx, PtKernelParams* p, const Program** prog_out
             p->bvh_nodes = ctx->bvh.nodes;
             p->bvh_tris = ctx->bvh.sorted_tris;
             p->bvh_ids = ctx->bvh.sorted_ids;
+        } else if (ctx->accel_mode == PT_ACCEL_CULL) {
+            p->cull = ctx->d_cull;
         }
     } else {
         PT_REQUIRE(ctx->have_spheres, PT_ERR_STATE, "no spheres uploaded: call pt_upload_spheres first");
@@ -388,6 +392,7 @@ PtStatus pt_upload_mesh(PtContext* ctx, const float* vertices, int32_t num_verti
     PT_HIP_TRY(hipMemsetAsync(ctx->d_tris + nt * PT_TRI_FLOATS, 0, PT_TRI_PAD * PT_TRI_FLOATS * sizeof(float), ctx->stream));
     PT_HIP_TRY(hipMalloc(&ctx->d_vnormals, nt * 9 * sizeof(float)));
     PT_HIP_TRY(hipMalloc(&ctx->d_gnormals, nt * 3 * sizeof(float)));
+    PT_HIP_TRY(hipMalloc(&ctx->d_cull, nt * PT_CULL_FLOATS * sizeof(float)));
     PT_HIP_TRY(hipMemcpyAsync(ctx->d_vertices, vertices, (size_t)num_vertices * 6 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     PT_HIP_TRY(hipMemcpyAsync(ctx->d_indices, indices, nt * 3 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -440,7 +445,7 @@ PtStatus pt_build_accel(PtContext* ctx) {
 
 PtStatus pt_set_accel_mode(PtContext* ctx, PtAccelMode mode) {
     PT_REQUIRE(ctx != nullptr, PT_ERR_INVALID_ARGUMENT, "null context");
-    PT_REQUIRE(mode == PT_ACCEL_AUTO || mode == PT_ACCEL_BRUTE || mode == PT_ACCEL_BVH, PT_ERR_INVALID_ARGUMENT, "unknown accel mode %d", (int)mode);
+    PT_REQUIRE(mode == PT_ACCEL_AUTO || mode == PT_ACCEL_BRUTE || mode == PT_ACCEL_BVH || mode == PT_ACCEL_CULL, PT_ERR_INVALID_ARGUMENT, "unknown accel mode %d", (int)mode);
     ctx->accel_mode = mode;
     return PT_OK;
 }

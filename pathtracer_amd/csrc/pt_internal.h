@@ -17,6 +17,9 @@
 // All-zero records appended to the triangle buffer: the triangle loop runs in steps of 4 and requests records up to
 // 5 past the last real one.
 #define PT_TRI_PAD 8
+// Cull record per triangle: unit normals of the three edge planes through the ray origin and of the front-facing
+// side (12 floats, padded to 16 so a lane fetches it with three aligned 16-byte loads).
+#define PT_CULL_FLOATS 16
 struct PtTriRecordLayout {
     enum { E1 = 0, E2 = 3, AP = 6, R = 9, E2R = 12 };
 };
@@ -67,6 +70,7 @@ struct PtKernelParams {
     const float* tris;                  // num_triangles x PT_TRI_FLOATS
     const float* vnormals;              // num_triangles x 9: the three vertex normals (na, nb, nc)
     const float* gnormals;              // num_triangles x 3: normalize(cross(e1, e2))
+    const float* cull;                  // num_triangles x PT_CULL_FLOATS, or null = no wave-level culling
     const float* bvh_nodes;             // LBVH traversal records, or null = test every triangle in index order
     const float* bvh_tris;              // triangle records in leaf order
     const int32_t* bvh_ids;             // triangle id of each leaf-order record
@@ -82,7 +86,7 @@ struct PtKernelParams {
 
 // Launchers (defined in pt_kernels.hip). All are asynchronous on `stream`.
 hipError_t pt_launch_prepare_triangles(const float* vertices, const uint32_t* indices, int32_t num_triangles,
-                                       const float ro[3], float* tris, float* vnormals, float* gnormals,
+                                       const float ro[3], float* tris, float* vnormals, float* gnormals, float* cull,
                                        hipStream_t stream);
 hipError_t pt_launch_fill_rgba(float* img, size_t num_pixels, float r, float g, float b, float a, hipStream_t stream);
 hipError_t pt_launch_render(const PtKernelParams& p, int program_kind, hipStream_t stream);

@@ -180,6 +180,95 @@ __device__ __forceinline__ Hit intersect_mesh(const float* __restrict__ tris, in
     return h;
 }
 
+// Wave-wide sum / max of a value held by ALL 64 lanes (EXEC must be full), without LDS: two quad permutes and two row
+// rotations leave every lane of a 16-lane row with the row's total, then the four row totals are combined through
+// scalar registers. The result is wave-uniform.
+template <bool MAX>
+__device__ __forceinline__ float wave_reduce(float v) {
+    auto comb = [](float a, float b) { return MAX ? __builtin_fmaxf(a, b) : a + b; };
+    auto dpp = [](float x, int ctrl_tag) {
+        const int xi = __float_as_int(x);
+        int r;
+        switch (ctrl_tag) {
+            case 0: r = __builtin_amdgcn_update_dpp(xi, xi, 0xB1, 0xf, 0xf, false); break;   // quad_perm [1,0,3,2]
+            case 1: r = __builtin_amdgcn_update_dpp(xi, xi, 0x4E, 0xf, 0xf, false); break;   // quad_perm [2,3,0,1]
+            case 2: r = __builtin_amdgcn_update_dpp(xi, xi, 0x124, 0xf, 0xf, false); break;  // row_ror:4
+            default: r = __builtin_amdgcn_update_dpp(xi, xi, 0x128, 0xf, 0xf, false); break; // row_ror:8
+        }
+        return __int_as_float(r);
+    };
+    v = comb(v, dpp(v, 0));
+    v = comb(v, dpp(v, 1));
+    v = comb(v, dpp(v, 2));
+    v = comb(v, dpp(v, 3));
+    const int vi = __float_as_int(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(vi, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(vi, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(vi, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(vi, 48));
+    return comb(comb(r0, r1), comb(r2, r3));
+}
+
+struct CullRec { float4 a, b, c; };  // nab.xyz nbc.x | nbc.yz nca.xy | nca.z front.xyz
+
+__device__ __forceinline__ CullRec load_cull(const float4* __restrict__ cull, int k, int n) {
+    CullRec r;
+    // out-of-range lanes get a record that always rejects (every plane faces away from any axis by more than 1)
+    r.a = make_float4(0.f, 0.f, 0.f, 0.f); r.b = r.a; r.c = r.a;
+    if (k < n) { r.a = cull[4 * (size_t)k]; r.b = cull[4 * (size_t)k + 1]; r.c = cull[4 * (size_t)k + 2]; }
+    return r;
+}
+
+// fs:125-174 for a whole wave at once, skipping triangles no ray of the wave can hit. All rays start at the camera,
+// so the wave's directions are bounded by a cone (axis = mean direction, opening from the largest chord to it);
+// 64 triangles are tested against that cone in parallel, one per lane, using the cull records; the survivors are
+// then tested exactly, in ascending index order, like the plain loop -- so the outcome is the plain loop's.
+// Must be called by all 64 lanes; `active` marks the lanes that carry a ray. `first` = this lane's cull record of
+// chunk 0, loaded once per kernel (for meshes of up to 64 triangles no record is fetched inside the ray loop).
+__device__ __forceinline__ Hit intersect_mesh_culled(const PtKernelParams& p, v3 rd, bool active, const CullRec& first, unsigned& tri_tests) {
+    Hit h;
+    h.t = 1.0e38f; h.id = -1; h.u = 0.f; h.v = 0.f; h.ood = 0.f;
+    const float w = active ? 1.0f : 0.0f;
+    v3 axis = V(wave_reduce<false>(rd.x * w), wave_reduce<false>(rd.y * w), wave_reduce<false>(rd.z * w));
+    const float len2 = dot3(axis, axis);
+    axis = axis * (len2 > 0.f ? __builtin_amdgcn_rsqf(len2) : 0.f);
+    const v3 dv = rd - axis;
+    // |d - axis| >= sin(angle) for unit vectors; the slack covers rounding here and in the exact test
+    const float spread = __builtin_sqrtf(wave_reduce<true>(active ? dot3(dv, dv) : 0.f)) + 3.0e-4f;
+    const float lim = -spread;
+    const int lane = threadIdx.x & 63;
+    const float4* __restrict__ cull = reinterpret_cast<const float4*>(p.cull);
+    const float4* __restrict__ recs = reinterpret_cast<const float4*>(p.tris);
+    const int n = p.num_triangles;
+    CullRec cr = first;
+    for (int base = 0; base < n; base += 64) {
+        // the next chunk's records are requested before this chunk's survivors are tested
+        CullRec nxt_cr = cr;
+        if (base + 64 < n) nxt_cr = load_cull(cull, base + 64 + lane, n);
+        const float d0 = axis.x * cr.a.x + (axis.y * cr.a.y + axis.z * cr.a.z);
+        const float d1 = axis.x * cr.a.w + (axis.y * cr.b.x + axis.z * cr.b.y);
+        const float d2 = axis.x * cr.b.z + (axis.y * cr.b.w + axis.z * cr.c.x);
+        const float d3 = axis.x * cr.c.y + (axis.y * cr.c.z + axis.z * cr.c.w);
+        const bool keep = (base + lane < n) & !((d0 < lim) | (d1 < lim) | (d2 < lim) | (d3 < lim));
+        unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
+        tri_tests += (unsigned)__builtin_popcountll(mask);
+        if (mask) {
+            int i = base + __builtin_ctzll(mask);
+            TriRec cur = load_rec(recs, i);
+            mask &= mask - 1;
+            while (true) {
+                const int inext = mask ? base + __builtin_ctzll(mask) : i;
+                const TriRec nxt = load_rec(recs, inext);  // requested before the current one is tested
+                test_triangle<false>(cur, i, rd, h);
+                if (!mask) break;
+                mask &= mask - 1;
+                cur = nxt;
+                i = inext;
+            }
+        }
+        cr = nxt_cr;
+    }
+    return h;
+}
+
 // Closest hit through the LBVH, one traversal per WAVE: the stack and the node being visited are wave-uniform (node
 // records arrive by scalar loads), each lane tests its own ray against the two child boxes, and a child is entered when
 // ANY lane may hit it. Rays of a wave are coherent (an 8x8 pixel tile and its near-mirror bounces), so the union of
@@ -383,14 +472,22 @@ __global__ __launch_bounds__(256) void pt_render_kernel(const PtKernelParams p) 
     rng.samples = (float)sample;
     rng.sx = 0.0f;
 
-    while (remaining > 0) {
+    CullRec cull0;
+    if (KIND == 3) cull0 = load_cull(reinterpret_cast<const float4*>(p.cull), threadIdx.x & 63, p.num_triangles);
+
+    // KIND 3 keeps all 64 lanes in the loop until the wave is done (its cull step is a wave-wide operation); lanes
+    // without a ray left are masked by `active`. The other kinds simply let finished lanes drop out.
+    while (KIND == 3 ? __builtin_amdgcn_ballot_w64(remaining > 0) != 0 : remaining > 0) {
+        const bool active = remaining > 0;
         Hit h;
         v3 N = V(0.f, 0.f, 0.f);
         if (KIND == 0) h = intersect_world(p.spheres, ro, rd, N);
         else if (KIND == 1) h = intersect_mesh(p.tris, p.num_triangles, rd);
-        else h = intersect_bvh(p, rd, s_stack[threadIdx.x >> 6], node_visits, tri_tests);
-        ++rays;
+        else if (KIND == 2) h = intersect_bvh(p, rd, s_stack[threadIdx.x >> 6], node_visits, tri_tests);
+        else h = intersect_mesh_culled(p, rd, active, cull0, tri_tests);
         ++trips;
+        if (KIND == 3 && !active) continue;
+        ++rays;
         const bool hit = h.id >= 0;
         if (hit) {
             if (KIND != 0) N = mesh_normal(p, h);
@@ -428,7 +525,7 @@ __global__ __launch_bounds__(256) void pt_render_kernel(const PtKernelParams p) 
         atomicAdd(&p.counters[0], wave_rays);
         atomicAdd(&p.counters[1], (unsigned long long)wave_trips * 64ull);
         if (p.tile_cost) atomicAdd(&p.tile_cost[tile], wave_trips);
-        if (KIND == 2) {
+        if (KIND >= 2) {
             atomicAdd(&p.counters[2], (unsigned long long)__builtin_amdgcn_readfirstlane(node_visits));
             atomicAdd(&p.counters[3], (unsigned long long)__builtin_amdgcn_readfirstlane(tri_tests));
         }
@@ -440,7 +537,7 @@ __global__ __launch_bounds__(256) void pt_primary_kernel(const PtKernelParams p)
     __shared__ uint32_t s_stack[KIND == 2 ? 4 : 1][KIND == 2 ? PT_BVH_STACK : 1];
     int x, y;
     const bool in_window = pixel_of_lane(p, (int)blockIdx.x, x, y);
-    if (KIND != 2 && !in_window) return;  // the BVH walk is per wave: every lane stays for the ballots
+    if (KIND < 2 && !in_window) return;  // the BVH walk and the cull step are per wave: every lane stays
     const size_t pix = (size_t)y * p.width + x;
     const v3 ro = V(p.ro[0], p.ro[1], p.ro[2]);
     const v3 rd = primary_direction(p, (float)x + 0.5f, (float)y + 0.5f);
@@ -450,6 +547,7 @@ __global__ __launch_bounds__(256) void pt_primary_kernel(const PtKernelParams p)
     else if (KIND == 1) h = intersect_mesh(p.tris, p.num_triangles, rd);
     unsigned nv = 0, tt = 0;
     if (KIND == 2) h = intersect_bvh(p, rd, s_stack[threadIdx.x >> 6], nv, tt);
+    if (KIND == 3) h = intersect_mesh_culled(p, rd, in_window, load_cull(reinterpret_cast<const float4*>(p.cull), threadIdx.x & 63, p.num_triangles), tt);
     if (!in_window) return;
     if (p.out_ids) p.out_ids[pix] = h.id;
     if (p.out_t) p.out_t[pix] = h.t;
@@ -460,7 +558,7 @@ __global__ __launch_bounds__(256) void pt_prepare_triangles_kernel(const float* 
                                                                     const uint32_t* __restrict__ indices, int n,
                                                                     float rox, float roy, float roz,
                                                                     float* __restrict__ tris, float* __restrict__ vnormals,
-                                                                    float* __restrict__ gnormals) {
+                                                                    float* __restrict__ gnormals, float* __restrict__ cull) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float* pa = vertices + 6 * (size_t)indices[3 * i];
@@ -483,6 +581,35 @@ __global__ __launch_bounds__(256) void pt_prepare_triangles_kernel(const float* 
     vn[6] = pc[3]; vn[7] = pc[4]; vn[8] = pc[5];
     const v3 g = normalize3(cross3(e1, e2));
     gnormals[3 * (size_t)i] = g.x; gnormals[3 * (size_t)i + 1] = g.y; gnormals[3 * (size_t)i + 2] = g.z;
+
+    // Cull record: four unit normals of planes through the ray origin. A direction can only pass the exact test
+    // when it lies on the inner side of the three edge planes (origin, two vertices) and sees the front of the
+    // triangle; a whole bundle of directions is skipped when its bounding cone lies outside one of them. Any plane
+    // that cannot be oriented reliably in fp32 (origin almost in the triangle's plane, sliver seen edge-on) is
+    // stored as zero, which never rejects. This arithmetic only decides what is SKIPPED; it is not part of the
+    // reference's numerics.
+    // Written with the short edge vectors so that small, distant triangles do not lose the planes to cancellation:
+    // A x B = A x e1, B x C = B x (e2 - e1), C x A = e2 x C, and the orientation A.(B x C) = A.(e1 x e2).
+    const v3 A = a - V(rox, roy, roz), B = b - V(rox, roy, roz), C = c - V(rox, roy, roz);
+    const v3 e12 = e2 - e1;
+    auto len = [](v3 x) { return __builtin_sqrtf(dot3(x, x)); };
+    const v3 nrm = cross3(e1, e2);
+    const float T = dot3(A, nrm);
+    const bool oriented = __builtin_fabsf(T) > 1.0e-4f * len(A) * len(nrm);
+    const float sgn = T > 0.f ? 1.f : -1.f;
+    auto unit_or_zero = [&len](v3 n, float scale, bool ok, float sign) -> v3 {
+        const float l = len(n);
+        if (!ok || !(l > 1.0e-4f * scale)) return V(0.f, 0.f, 0.f);
+        return n * (sign / l);
+    };
+    const v3 nab = unit_or_zero(cross3(A, e1), len(A) * len(e1), oriented, sgn);
+    const v3 nbc = unit_or_zero(cross3(B, e12), len(B) * len(e12), oriented, sgn);
+    const v3 nca = unit_or_zero(cross3(e2, C), len(C) * len(e2), oriented, sgn);
+    const v3 front = unit_or_zero(cross3(e2, e1), len(e1) * len(e2), true, 1.f);  // det = dot(rd, e2 x e1)
+    float* cr = cull + (size_t)i * PT_CULL_FLOATS;
+    cr[0] = nab.x; cr[1] = nab.y; cr[2] = nab.z; cr[3] = nbc.x;
+    cr[4] = nbc.y; cr[5] = nbc.z; cr[6] = nca.x; cr[7] = nca.y;
+    cr[8] = nca.z; cr[9] = front.x; cr[10] = front.y; cr[11] = front.z;
 }
 
 // Present pass: the reference's copy.fs (pow(rgb, 0.454545), copy.fs:18) followed by the float -> 8-bit conversion
@@ -541,11 +668,11 @@ int window_tiles(const PtKernelParams& p) { return ((p.win_w + 15) / 16) * ((p.w
 }  // namespace
 
 hipError_t pt_launch_prepare_triangles(const float* vertices, const uint32_t* indices, int32_t num_triangles,
-                                       const float ro[3], float* tris, float* vnormals, float* gnormals,
+                                       const float ro[3], float* tris, float* vnormals, float* gnormals, float* cull,
                                        hipStream_t stream) {
     if (num_triangles <= 0) return hipSuccess;
     hipLaunchKernelGGL(pt_prepare_triangles_kernel, dim3((num_triangles + 255) / 256), dim3(256), 0, stream, vertices,
-                       indices, num_triangles, ro[0], ro[1], ro[2], tris, vnormals, gnormals);
+                       indices, num_triangles, ro[0], ro[1], ro[2], tris, vnormals, gnormals, cull);
     return hipGetLastError();
 }
 
@@ -574,15 +701,17 @@ hipError_t pt_launch_schedule_tiles(uint32_t* tile_cost, uint32_t* tile_order, i
 hipError_t pt_launch_render(const PtKernelParams& p, int program_kind, hipStream_t stream) {
     if (p.win_w <= 0 || p.win_h <= 0 || p.num_samples <= 0) return hipSuccess;
     if (program_kind == 0) hipLaunchKernelGGL(pt_render_kernel<0>, dim3(window_tiles(p)), dim3(256), 0, stream, p);
-    else if (!p.bvh_nodes) hipLaunchKernelGGL(pt_render_kernel<1>, dim3(window_tiles(p)), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL(pt_render_kernel<2>, dim3(window_tiles(p)), dim3(256), 0, stream, p);
+    else if (p.bvh_nodes) hipLaunchKernelGGL(pt_render_kernel<2>, dim3(window_tiles(p)), dim3(256), 0, stream, p);
+    else if (p.cull) hipLaunchKernelGGL(pt_render_kernel<3>, dim3(window_tiles(p)), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(pt_render_kernel<1>, dim3(window_tiles(p)), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 
 hipError_t pt_launch_primary(const PtKernelParams& p, int program_kind, hipStream_t stream) {
     if (p.win_w <= 0 || p.win_h <= 0) return hipSuccess;
     if (program_kind == 0) hipLaunchKernelGGL(pt_primary_kernel<0>, dim3(window_tiles(p)), dim3(256), 0, stream, p);
-    else if (!p.bvh_nodes) hipLaunchKernelGGL(pt_primary_kernel<1>, dim3(window_tiles(p)), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL(pt_primary_kernel<2>, dim3(window_tiles(p)), dim3(256), 0, stream, p);
+    else if (p.bvh_nodes) hipLaunchKernelGGL(pt_primary_kernel<2>, dim3(window_tiles(p)), dim3(256), 0, stream, p);
+    else if (p.cull) hipLaunchKernelGGL(pt_primary_kernel<3>, dim3(window_tiles(p)), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(pt_primary_kernel<1>, dim3(window_tiles(p)), dim3(256), 0, stream, p);
     return hipGetLastError();
 }

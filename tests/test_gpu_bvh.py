@@ -33,7 +33,7 @@ def both_modes(t, verts, idx, cam, W, H, normal_mode, spp=3, window=None):
     t.set_uniforms(cam, len(idx), 10)
     t.build_accel()
     res = {}
-    for name, mode in (("brute", capi.ACCEL_BRUTE), ("bvh", capi.ACCEL_BVH)):
+    for name, mode in (("brute", capi.ACCEL_BRUTE), ("bvh", capi.ACCEL_BVH), ("cull", capi.ACCEL_CULL)):
         t.set_accel_mode(mode)
         t.target_clear()
         t.reset_stats()
@@ -48,11 +48,13 @@ def both_modes(t, verts, idx, cam, W, H, normal_mode, spp=3, window=None):
 
 
 def assert_same(res):
-    b, a = res["brute"], res["bvh"]
-    assert np.array_equal(a[0], b[0]), f"{(a[0] != b[0]).sum()} primary ids differ"
-    assert n_bit_mismatch(a[1], b[1]) == 0
-    assert n_bit_mismatch(a[2], b[2]) == 0
-    assert a[3] == b[3]
+    b = res["brute"]
+    for other in ("bvh", "cull"):
+        a = res[other]
+        assert np.array_equal(a[0], b[0]), f"{other}: {(a[0] != b[0]).sum()} primary ids differ"
+        assert n_bit_mismatch(a[1], b[1]) == 0, other
+        assert n_bit_mismatch(a[2], b[2]) == 0, other
+        assert a[3] == b[3], other
 
 
 @pytest.mark.parametrize("name", ["monkey_mesh_128", "cornell_geo_128", "suzanne_geo_96"])
@@ -113,6 +115,40 @@ def test_random_soup_and_degenerate_layouts(tracer):
         res = both_modes(tracer, verts, idx, cam, W, H, 1, spp=2)
         assert_same(res)
         assert (res["bvh"][0] >= 0).sum() > 1000
+
+
+def test_culling_is_conservative_in_awkward_views(tracer):
+    """Views that stress the wave-level cull and the padded boxes: camera inside the mesh's bounding box, camera lying
+    in the plane of many triangles, needle-thin triangles, and a very wide field of view (large ray bundles)."""
+    rng = np.random.default_rng(23)
+    g = 24
+    xs, zs = np.meshgrid(np.linspace(-4, 4, g + 1), np.linspace(0.5, 9, g + 1))
+    floor = []
+    for j in range(g):
+        for i in range(g):
+            a, b, c, d = [np.array([xs[j + dj, i + di], 0.0, zs[j + dj, i + di]]) for dj, di in ((0, 0), (0, 1), (1, 1), (1, 0))]
+            floor += [[a, b, c], [a, c, d]]                      # seen from above
+    floor = np.array(floor, np.float32)
+    needles = np.array([[[x, -1.0, 5.0], [x + 1e-3, -1.0, 5.0], [x + 5e-4, 2.0, 5.0 + 0.3 * k]] for k, x in enumerate(np.linspace(-3, 3, 200))],
+                       np.float32)[:, ::-1].copy()
+    nt = 800
+    base = rng.uniform(-2.5, 2.5, (nt, 1, 3)) + np.array([0, 0, 1.0])
+    around = (base + rng.uniform(-0.6, 0.6, (nt, 3, 3))).astype(np.float32)   # surrounds the camera
+    tris = np.concatenate([floor, needles, around])
+    verts = np.concatenate([tris.reshape(-1, 3), np.zeros((len(tris) * 3, 3), np.float32)], 1)
+    idx = np.arange(len(verts), dtype=np.uint32).reshape(-1, 3)
+    views = [(100.0, (0.0, 1.0, 0.0), (0.0, 0.2, 5.0)),     # above the floor, very wide
+             (70.0, (0.1, 0.0, 0.2), (0.0, 0.0, 6.0)),      # eye exactly in the floor's plane
+             (140.0, (0.0, 0.5, 1.0), (0.3, 0.4, 4.0))]     # inside the cloud, extreme field of view
+    for fov, eye, target in views:
+        cam = po.camera(fov, 160, 96, eye, target, (0.0, 1.0, 0.0))
+        res = both_modes(tracer, verts, idx, cam, 160, 96, 1, spp=2)
+        assert_same(res)
+        assert (res["brute"][0] >= 0).sum() > 500
+        scene = po.Scene(verts, idx, *po.reference_spheres_and_materials())
+        u = po.uniforms(cam, 160, 96, len(idx), 10, 1, 1)
+        oids, _, _ = po.primary(scene, u, threads=8)
+        assert np.array_equal(res["cull"][0], oids)
 
 
 def test_million_triangle_scene_crops(tracer):

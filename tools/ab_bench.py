@@ -16,8 +16,6 @@ sys.path.insert(0, ROOT)
 
 VARIANTS = {
     "product": [],
-    "simple": ["-DPT_V_SIMPLE"],
-    "no_detskip": ["-DPT_V_NO_DETSKIP"],
 }
 
 
@@ -30,6 +28,7 @@ def main():
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--only", default=None)
+    ap.add_argument("--accel", type=int, default=0, help="0 auto, 1 brute, 2 bvh, 3 cull")
     args = ap.parse_args()
     from pathtracer_amd import build as ptbuild
     names = [v for v in VARIANTS if not args.only or v in args.only.split(",")]
@@ -44,7 +43,8 @@ def main():
     tracers, ref = {}, None
     for v in names:
         t = Tracer(0, os.path.join(ROOT, "pathtracer_amd", "lib", f"libpt_hip__{v}.so"))
-        scene.upload(t)
+        scene.upload(t, accel=False)
+        t.set_accel_mode(args.accel)
         t.target_create(scene.width, scene.height)
         t.enable_timing(True)
         t.dispatch(1, 2, 1)
@@ -70,7 +70,7 @@ def main():
         rays, u = util[v]
         ms = statistics.median(times[v])
         print(json.dumps({"variant": v, "median_ms": round(ms, 3), "min_ms": round(min(times[v]), 3),
-                          "Grays_per_s": round(rays / ms * 1e-6, 2), "lane_utilisation": round(u, 4),
+                          "Grays_per_s": round(rays / ms * 1e-6, 2), "lane_utilisation": round(u, 4), "tri_records_per_wave_ray": round(st["bvh_triangle_fetches"] * 64 / max(1, st["lane_slots"]), 2),
                           "same_image_as_first": tracers[v][1]}))
 
 

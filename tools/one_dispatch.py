@@ -17,7 +17,7 @@ def main():
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--lib", default=None)
-    ap.add_argument("--accel", default="auto", choices=["auto", "brute", "bvh"])
+    ap.add_argument("--accel", default="auto", choices=["auto", "brute", "bvh", "cull"])
     args = ap.parse_args()
     from pathtracer_amd import Tracer
     from pathtracer_amd.scenes import SceneData
@@ -34,7 +34,7 @@ def main():
         t.set_accel_mode(2)
     else:
         build_s = 0.0
-        t.set_accel_mode(1 if args.accel == "brute" else 0)
+        t.set_accel_mode({"brute": 1, "cull": 3, "auto": 0}[args.accel])
     t.enable_timing(True)
     t.dispatch(1, 1, 1)
     t.finish()
@@ -49,7 +49,9 @@ def main():
     ms = st["total_dispatch_ms"] / st["dispatches"]
     print(json.dumps({"workload": args.workload, "size": [scene.width, scene.height], "spp": args.spp, "triangles": scene.num_triangles,
                       "accel": args.accel, "bvh_build_s": round(build_s, 4), "kernel_ms": ms, "per_rep_ms": per_rep, "Grays_per_s": st["rays"] / st["dispatches"] / ms * 1e-6,
-                      "rays_per_sample": st["rays"] / st["samples"], "lane_utilisation": st["rays"] / st["lane_slots"]}))
+                      "rays_per_sample": st["rays"] / st["samples"], "lane_utilisation": st["rays"] / st["lane_slots"],
+                      "triangle_records_per_wave_ray": st["bvh_triangle_fetches"] * 64 / st["lane_slots"],
+                      "node_records_per_wave_ray": st["bvh_node_fetches"] * 64 / st["lane_slots"]}))
     t.close()
 
 
