@@ -465,7 +465,7 @@ static PtStatus target_common(PtContext* ctx, int32_t width, int32_t height) {
     const size_t n = (size_t)width * height;
     PT_HIP_TRY(hipMalloc(&ctx->d_ids, n * sizeof(int32_t)));
     PT_HIP_TRY(hipMalloc(&ctx->d_t, n * sizeof(float)));
-    const size_t tiles = (size_t)((width + 15) / 16) * ((height + 15) / 16);
+    const size_t tiles = (size_t)PT_TILES_ACROSS(width) * PT_TILES_ACROSS(height);
     PT_HIP_TRY(hipMalloc(&ctx->d_tile_cost, tiles * sizeof(uint32_t)));
     PT_HIP_TRY(hipMalloc(&ctx->d_tile_order, tiles * sizeof(uint32_t)));
     ctx->sched_have_cost = false;
@@ -568,7 +568,7 @@ PtStatus pt_dispatch(PtContext* ctx, int32_t first_sample, int32_t num_samples, 
     // It is only a scheduling hint (any order renders the same image), so stale costs after a camera or scene change
     // are harmless.
     if (ctx->sched_enabled) {
-        const int tiles = ((ctx->win[2] + 15) / 16) * ((ctx->win[3] + 15) / 16);
+        const int tiles = PT_TILES_ACROSS(ctx->win[2]) * PT_TILES_ACROSS(ctx->win[3]);
         const bool same_window = memcmp(ctx->sched_win, ctx->win, sizeof ctx->win) == 0;
         if (ctx->sched_have_cost && same_window) {
             PT_HIP_TRY(pt_launch_schedule_tiles(ctx->d_tile_cost, ctx->d_tile_order, tiles, ctx->stream));

@@ -397,7 +397,7 @@ __device__ __forceinline__ void shade(Rng& rng, float& energy, v3& rd, v3 N) {
     energy = energy * (diffuse + specular);
 }
 
-// Which 16x16 pixel tile this block renders. Blocks are handed to CUs in blockIdx order, so `tile_order` (a permutation
+// Which pixel tile this block renders. Blocks are handed to CUs in blockIdx order, so `tile_order` (a permutation
 // of the tile numbers, most expensive first, made from the previous dispatch's per-tile cost) keeps the long tiles from
 // starting last. Any permutation gives the same image.
 __device__ __forceinline__ int tile_of_block(const PtKernelParams& p) {
@@ -405,12 +405,12 @@ __device__ __forceinline__ int tile_of_block(const PtKernelParams& p) {
 }
 
 __device__ __forceinline__ bool pixel_of_lane(const PtKernelParams& p, int tile, int& x, int& y) {
-    // 256 threads = 4 waves; a wave covers an 8x8 pixel tile, the block a 16x16 tile.
+    // a wave covers an 8x8 pixel block; the workgroup's PT_TILE_WAVES waves tile a PT_TILE_DIM square
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tiles_x = (p.win_w + 15) >> 4;
+    const int tiles_x = PT_TILES_ACROSS(p.win_w);
     const int tx = tile % tiles_x, ty = tile / tiles_x;
-    const int lx = tx * 16 + (wave & 1) * 8 + (lane & 7);
-    const int ly = ty * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const int lx = tx * PT_TILE_DIM + (wave & 1) * 8 + (lane & 7);
+    const int ly = ty * PT_TILE_DIM + (wave >> 1) * 8 + (lane >> 3);
     x = p.win_x0 + lx;
     y = p.win_y0 + ly;
     return lx < p.win_w && ly < p.win_h;
@@ -442,8 +442,8 @@ __device__ __forceinline__ unsigned __reduce_max_trips(unsigned v) {
 }
 
 template <int KIND>  // PtProgramKind
-__global__ __launch_bounds__(256) void pt_render_kernel(const PtKernelParams p) {
-    __shared__ uint32_t s_stack[KIND == 2 ? 4 : 1][KIND == 2 ? PT_BVH_STACK : 1];
+__global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKernelParams p) {
+    __shared__ uint32_t s_stack[KIND == 2 ? PT_TILE_WAVES : 1][KIND == 2 ? PT_BVH_STACK : 1];
     int x, y;
     const int tile = tile_of_block(p);
     const bool in_window = pixel_of_lane(p, tile, x, y);
@@ -533,8 +533,8 @@ __global__ __launch_bounds__(256) void pt_render_kernel(const PtKernelParams p) 
 }
 
 template <int KIND>
-__global__ __launch_bounds__(256) void pt_primary_kernel(const PtKernelParams p) {
-    __shared__ uint32_t s_stack[KIND == 2 ? 4 : 1][KIND == 2 ? PT_BVH_STACK : 1];
+__global__ __launch_bounds__(PT_TILE_THREADS) void pt_primary_kernel(const PtKernelParams p) {
+    __shared__ uint32_t s_stack[KIND == 2 ? PT_TILE_WAVES : 1][KIND == 2 ? PT_BVH_STACK : 1];
     int x, y;
     const bool in_window = pixel_of_lane(p, (int)blockIdx.x, x, y);
     if (KIND < 2 && !in_window) return;  // the BVH walk and the cull step are per wave: every lane stays
@@ -663,7 +663,7 @@ __global__ __launch_bounds__(1024) void pt_schedule_tiles_kernel(uint32_t* __res
     for (int i = threadIdx.x; i < n; i += blockDim.x) cost[i] = 0;
 }
 
-int window_tiles(const PtKernelParams& p) { return ((p.win_w + 15) / 16) * ((p.win_h + 15) / 16); }
+int window_tiles(const PtKernelParams& p) { return PT_TILES_ACROSS(p.win_w) * PT_TILES_ACROSS(p.win_h); }
 
 }  // namespace
 
@@ -700,18 +700,18 @@ hipError_t pt_launch_schedule_tiles(uint32_t* tile_cost, uint32_t* tile_order, i
 
 hipError_t pt_launch_render(const PtKernelParams& p, int program_kind, hipStream_t stream) {
     if (p.win_w <= 0 || p.win_h <= 0 || p.num_samples <= 0) return hipSuccess;
-    if (program_kind == 0) hipLaunchKernelGGL(pt_render_kernel<0>, dim3(window_tiles(p)), dim3(256), 0, stream, p);
-    else if (p.bvh_nodes) hipLaunchKernelGGL(pt_render_kernel<2>, dim3(window_tiles(p)), dim3(256), 0, stream, p);
-    else if (p.cull) hipLaunchKernelGGL(pt_render_kernel<3>, dim3(window_tiles(p)), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL(pt_render_kernel<1>, dim3(window_tiles(p)), dim3(256), 0, stream, p);
+    if (program_kind == 0) hipLaunchKernelGGL(pt_render_kernel<0>, dim3(window_tiles(p)), dim3(PT_TILE_THREADS), 0, stream, p);
+    else if (p.bvh_nodes) hipLaunchKernelGGL(pt_render_kernel<2>, dim3(window_tiles(p)), dim3(PT_TILE_THREADS), 0, stream, p);
+    else if (p.cull) hipLaunchKernelGGL(pt_render_kernel<3>, dim3(window_tiles(p)), dim3(PT_TILE_THREADS), 0, stream, p);
+    else hipLaunchKernelGGL(pt_render_kernel<1>, dim3(window_tiles(p)), dim3(PT_TILE_THREADS), 0, stream, p);
     return hipGetLastError();
 }
 
 hipError_t pt_launch_primary(const PtKernelParams& p, int program_kind, hipStream_t stream) {
     if (p.win_w <= 0 || p.win_h <= 0) return hipSuccess;
-    if (program_kind == 0) hipLaunchKernelGGL(pt_primary_kernel<0>, dim3(window_tiles(p)), dim3(256), 0, stream, p);
-    else if (p.bvh_nodes) hipLaunchKernelGGL(pt_primary_kernel<2>, dim3(window_tiles(p)), dim3(256), 0, stream, p);
-    else if (p.cull) hipLaunchKernelGGL(pt_primary_kernel<3>, dim3(window_tiles(p)), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL(pt_primary_kernel<1>, dim3(window_tiles(p)), dim3(256), 0, stream, p);
+    if (program_kind == 0) hipLaunchKernelGGL(pt_primary_kernel<0>, dim3(window_tiles(p)), dim3(PT_TILE_THREADS), 0, stream, p);
+    else if (p.bvh_nodes) hipLaunchKernelGGL(pt_primary_kernel<2>, dim3(window_tiles(p)), dim3(PT_TILE_THREADS), 0, stream, p);
+    else if (p.cull) hipLaunchKernelGGL(pt_primary_kernel<3>, dim3(window_tiles(p)), dim3(PT_TILE_THREADS), 0, stream, p);
+    else hipLaunchKernelGGL(pt_primary_kernel<1>, dim3(window_tiles(p)), dim3(PT_TILE_THREADS), 0, stream, p);
     return hipGetLastError();
 }

@@ -15,7 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 VARIANTS = {
-    "product": [],
+    "waves4": [],
+    "waves1": ["-DPT_TILE_WAVES=1"],
 }
 
 
@@ -43,7 +44,7 @@ def main():
     tracers, ref = {}, None
     for v in names:
         t = Tracer(0, os.path.join(ROOT, "pathtracer_amd", "lib", f"libpt_hip__{v}.so"))
-        scene.upload(t, accel=False)
+        scene.upload(t, accel=(args.accel in (0, 2)))
         t.set_accel_mode(args.accel)
         t.target_create(scene.width, scene.height)
         t.enable_timing(True)
