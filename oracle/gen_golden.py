@@ -78,24 +78,33 @@ def harness(job, tmp):
     return img, dumps, info
 
 
-def scene_files(tmp, scene):
+def scene_files(tmp, scene, with_material_ids=False):
     scene.spheres.tofile(f"{tmp}/spheres.f32")
-    scene.materials.tofile(f"{tmp}/materials.f32")
+    mats = np.zeros((10, 4), np.float32)      # the reference's materials texture is 10 texels wide
+    mats[:min(10, len(scene.materials))] = scene.materials[:10]
+    mats.tofile(f"{tmp}/materials.f32")
     scene.vertices.tofile(f"{tmp}/vertices.f32")
-    scene.indices.tofile(f"{tmp}/indices.u32")
     texw = max(1024, 2 * len(scene.vertices), len(scene.indices))
-    return {"spheres": f"{tmp}/spheres.f32", "materials": f"{tmp}/materials.f32", "vertices": f"{tmp}/vertices.f32",
-            "indices": f"{tmp}/indices.u32", "num_triangles": len(scene.indices), "tex_width": texw}
+    out = {"spheres": f"{tmp}/spheres.f32", "materials": f"{tmp}/materials.f32", "vertices": f"{tmp}/vertices.f32",
+           "indices": f"{tmp}/indices.u32", "num_triangles": len(scene.indices), "tex_width": texw}
+    if with_material_ids:
+        np.concatenate([scene.indices, scene.material_ids.astype(np.uint32)[:, None]], 1).astype(np.uint32).tofile(f"{tmp}/indices.u32")
+        out["index_components"] = 4
+    else:
+        scene.indices.tofile(f"{tmp}/indices.u32")
+    return out
 
 
 def cam_floats(cam):
     return [float(np.float32(x)) for x in cam]
 
 
-def render_case(name, scene, cam, W, H, variant, normal_mode, spp_list, crop=None, depth=10):
+def render_case(name, scene, cam, W, H, variant, normal_mode, spp_list, crop=None, depth=10, shading_mode=0):
     """Runs the id-instrumented and the radiance variants on llvmpipe; checks the oracle; returns the fixture."""
     tmp = tempfile.mkdtemp(prefix="lp_")
+    os.makedirs(tmp + "/m")
     base = scene_files(tmp, scene)
+    rad_base = scene_files(tmp + "/m", scene, True) if shading_mode else None
     base.update({"width": W, "height": H, "depth": depth, "camera": cam_floats(cam)})
     if crop:
         base["crop"] = list(crop)
@@ -108,13 +117,18 @@ def render_case(name, scene, cam, W, H, variant, normal_mode, spp_list, crop=Non
     job = dict(base, num_samples=max(spp_list), dump_after=list(spp_list))
     if rad_edit:
         job["edits"] = f"{EDITS}/{rad_edit}.txt"
+    if shading_mode:
+        assert variant == po.VARIANT_MESH and normal_mode == po.NORMALS_GEOMETRIC
+        job.update(rad_base)
+        job["edits"] = f"{EDITS}/mesh_materials_geo.txt"
     if not crop:
         job["present_out"] = f"{tmp}/present.u8"   # the reference's copy.fs pass over the final image
     _, dumps, info = harness(job, tmp)
     present = None if crop else np.fromfile(f"{tmp}/present.u8", np.uint8).reshape(H, W, 4)
     shutil.rmtree(tmp)
 
-    fx = {"width": W, "height": H, "depth": depth, "variant": variant, "normal_mode": normal_mode,
+    fx = {"width": W, "height": H, "depth": depth, "variant": variant, "normal_mode": normal_mode, "shading_mode": shading_mode,
+          "material_ids": scene.material_ids,
           "camera": np.asarray(cam, np.float32), "crop": np.asarray(crop if crop else (0, 0, W, H), np.int32),
           "vertices": scene.vertices, "indices": scene.indices, "spheres": scene.spheres, "materials": scene.materials,
           "lp_id": idimg[..., 0].astype(np.int32), "lp_t": idimg[..., 1].copy(),
@@ -128,7 +142,7 @@ def render_case(name, scene, cam, W, H, variant, normal_mode, spp_list, crop=Non
 
     # ---- immediate check of the restatement against what llvmpipe produced
     x0, y0, w, h = fx["crop"]
-    u = po.uniforms(cam, W, H, len(scene.indices), depth, variant, normal_mode)
+    u = po.uniforms(cam, W, H, len(scene.indices), depth, variant, normal_mode, shading_mode)
     ids, ts, rds = po.primary(scene, u, window=(x0, y0, w, h), threads=8)
     ids, ts, rds = ids[y0:y0 + h, x0:x0 + w], ts[y0:y0 + h, x0:x0 + w], rds[y0:y0 + h, x0:x0 + w]
     hit = fx["lp_id"] >= 0
@@ -258,6 +272,17 @@ def main():
 
     for (name, sc, cam, W, H, variant, nm, spp, crop) in cases:
         fx, rep = render_case(name, sc, cam, W, H, variant, nm, spp, crop)
+        np.savez_compressed(f"{GOLD}/case_{name}.npz", **fx)
+        report.append(rep)
+
+    # ---- build-defined diffuse/emissive mode (edits/mesh_materials_geo.txt), MTL materials of the Cornell box and cube
+    ctab = po.material_table_from_mtl(objs["cornell_box"]["mat_values"])
+    cids = np.where(objs["cornell_box"]["mat_ids"] < 0, len(ctab) - 1, objs["cornell_box"]["mat_ids"])
+    cornell_m = po.Scene(cv, ci, sph, ctab, cids)
+    mcases = [("cornell_materials_128", cornell_m, ccam(128, 128), 128, 128, [1, 2, 16], None),
+              ("cornell_materials_1080p_crop", cornell_m, ccam(1920, 1080), 1920, 1080, [1, 4], (700, 300, 64, 64))]
+    for (name, sc, cam, W, H, spp, crop) in mcases:
+        fx, rep = render_case(name, sc, cam, W, H, po.VARIANT_MESH, po.NORMALS_GEOMETRIC, spp, crop, shading_mode=1)
         np.savez_compressed(f"{GOLD}/case_{name}.npz", **fx)
         report.append(rep)
 

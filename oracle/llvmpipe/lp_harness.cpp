@@ -179,6 +179,7 @@ struct Job {
     float camera[12] = {0};             // position, lowerLeftCorner, horizontal, vertical
     int num_triangles = 0;
     int tex_width = 1024;               // reference: 1024 (PathTracer.cpp:1274,1287)
+    int index_components = 3;           // reference: RGB32UI (PathTracer.cpp:1274); 4 = RGBA32UI carrying a material id
     std::string spheres, materials, vertices, indices, init_accum, out;
     std::string present_out;            // if set: also run the reference's present pass (copy.fs) into an RGBA8 target
     std::vector<int> dump_after;        // also dump out.<k>.f32 after these 1-based pass counts
@@ -218,6 +219,7 @@ static Job parse_job(const char* path) {
         else if (k == "camera") { for (int i = 0; i < 12; i++) { std::string t; ss >> t; j.camera[i] = strtof(t.c_str(), nullptr); } }
         else if (k == "num_triangles") ss >> j.num_triangles;
         else if (k == "tex_width") ss >> j.tex_width;
+        else if (k == "index_components") ss >> j.index_components;
         else if (k == "spheres") ss >> j.spheres;
         else if (k == "materials") ss >> j.materials;
         else if (k == "vertices") ss >> j.vertices;
@@ -392,7 +394,8 @@ int main(int argc, char** argv) {
     std::vector<float> spheres = load_f32(job.spheres, 40);
     std::vector<float> materials = load_f32(job.materials, 40);
     std::vector<float> vertices = load_f32(job.vertices, (size_t)TW * 3);
-    std::vector<uint32_t> indices = load_u32(job.indices, (size_t)TW * 3);
+    const int IC = job.index_components == 4 ? 4 : 3;
+    std::vector<uint32_t> indices = load_u32(job.indices, (size_t)TW * IC);
     if ((size_t)job.num_triangles > (size_t)TW) die("num_triangles exceeds tex_width");
     if (vertices.size() > (size_t)TW * 3) die("vertex data exceeds tex_width texels");
 
@@ -413,7 +416,8 @@ int main(int argc, char** argv) {
     glTexParameteri(GL_TEXTURE_RECTANGLE, GL_TEXTURE_MAG_FILTER, GL_NEAREST);
     glTexParameteri(GL_TEXTURE_RECTANGLE, GL_TEXTURE_WRAP_S, GL_CLAMP_TO_EDGE);
     glTexParameteri(GL_TEXTURE_RECTANGLE, GL_TEXTURE_WRAP_T, GL_CLAMP_TO_EDGE);
-    glTexImage2D(GL_TEXTURE_RECTANGLE, 0, GL_RGB32UI, TW, 1, 0, GL_RGB_INTEGER, GL_UNSIGNED_INT, indices.data());
+    glTexImage2D(GL_TEXTURE_RECTANGLE, 0, IC == 4 ? GL_RGBA32UI : GL_RGB32UI, TW, 1, 0, IC == 4 ? GL_RGBA_INTEGER : GL_RGB_INTEGER,
+                 GL_UNSIGNED_INT, indices.data());
     GLCHECK("indices texture");
     glGenTextures(1, &t_vtx);
     glBindTexture(GL_TEXTURE_RECTANGLE, t_vtx);

@@ -38,6 +38,7 @@ typedef struct PtoScene {
     const float* vertices;    /* 6 per vertex: position at texel 2i, normal at texel 2i+1 (PathTracer.cpp:71-75,1287) */
     const float* spheres;     /* 10 x (cx,cy,cz,r) (PathTracer.cpp:589-592,1258) */
     const float* materials;   /* 10 x (r,g,b,type); fetched then overwritten by the shader (fs:228-229) */
+    const int32_t* material_ids; /* per triangle, 0..9; only read in the build-defined "materials" shading mode */
 } PtoScene;
 
 typedef struct PtoUniforms {
@@ -47,6 +48,9 @@ typedef struct PtoUniforms {
     int32_t width, height;                                /* textureSize(u_Texture,0) (fs:381) */
     int32_t variant;      /* 0 = "world": IntersectWorld call (fs:395, as committed); 1 = "mesh": IntersectMesh call (fs:396) */
     int32_t normal_mode;  /* 0 = interpolated vertex normals (fs:165); 1 = geometric normal, the shader's alternative (fs:166) */
+    int32_t shading_mode; /* 0 = the shader as it is (Phong lobe, material ignored, origin fixed);
+                             1 = build-defined diffuse/emissive mode = the shader with the edits of
+                                 oracle/llvmpipe/edits/mesh_materials_geo.txt (pinned against llvmpipe running exactly that) */
 } PtoUniforms;
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -293,6 +297,24 @@ static void shade(PixelCtx* p, v3* attenuation, v3* rd, v3 N) {
     *attenuation = scale(*attenuation, k);
 }
 
+/* Shade() of the "materials" variant (edits/mesh_materials_geo.txt, replacing fs:229): material = (r,g,b,e);
+ * e > 0: emitter of radiance rgb*e, path ends; else Lambert of albedo rgb, cosine-weighted direction about N from the
+ * shader's own GetTangentSpace/randomHemisphere(r1, 1.0) (fs:44-76), and the origin moves to the hit point (fs:274). */
+static void shade_materials(PixelCtx* p, const float* m, v3* attenuation, v3* ro, v3* rd, v3 P, v3 N, v3* emitted) {
+    if (m[3] > 0.0f) {
+        *emitted = mul(*attenuation, V(m[0] * m[3], m[1] * m[3], m[2] * m[3]));
+        *attenuation = V(0.0f, 0.0f, 0.0f);
+        return;
+    }
+    float r1 = rng_rand01(p);
+    v3 c0, c1, c2;
+    tangent_space(N, &c0, &c1, &c2);
+    v3 h = random_hemisphere(p, r1, 1.0f);
+    *rd = add(add(scale(c0, h.x), scale(c1, h.y)), scale(c2, h.z));
+    *ro = add(P, scale(*rd, 0.0001f));
+    *attenuation = mul(*attenuation, V(m[0], m[1], m[2]));
+}
+
 typedef struct { int id; float t; v3 rd; } Primary;
 
 /* fs:376-410: one invocation of main() up to "accum += energy * skyLight"; returns accum. */
@@ -312,6 +334,7 @@ static v3 trace_pixel(const PtoScene* sc, const PtoUniforms* u, int px, int py, 
     if (prim) { prim->id = -1; prim->t = 0.0f; prim->rd = rd; }
 
     v3 energy = V(1.0f, 1.0f, 1.0f);
+    v3 emitted = V(0.0f, 0.0f, 0.0f);
     for (int level = 0; level < u->depth; level++) {
         float rec_t = 1.0e38f;
         v3 rec_p = V(0, 0, 0), rec_n = V(0, 0, 0);
@@ -320,12 +343,16 @@ static v3 trace_pixel(const PtoScene* sc, const PtoUniforms* u, int px, int py, 
         else hit = intersect_mesh(sc, u, ro, rd, &rec_p, &rec_n, &rec_t);
         if (rays) (*rays)++;
         if (prim && level == 0) { prim->id = hit; prim->t = hit >= 0 ? rec_t : 1.0e38f; }
-        if (hit >= 0) shade(&p, &energy, &rd, rec_n);
+        if (hit >= 0) {
+            if (u->shading_mode == 0) shade(&p, &energy, &rd, rec_n);
+            else shade_materials(&p, sc->materials + 4 * sc->material_ids[hit], &energy, &ro, &rd, rec_p, rec_n, &emitted);
+        }
         int any_energy = (energy.x != 0.0f) || (energy.y != 0.0f) || (energy.z != 0.0f);
         if (!any_energy || hit < 0) break;
     }
     float t = 0.5f * (rd.y + 1.0f);
     v3 sky = add(V(1.0f - t, 1.0f - t, 1.0f - t), scale(V(0.5f, 0.7f, 1.0f), t));
+    if (u->shading_mode != 0) return add(mul(energy, sky), emitted);  /* vec3(0) + (energy*sky + g_emitted) */
     return mul(energy, sky);  /* vec3(0) + energy*sky */
 }
 

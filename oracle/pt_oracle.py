@@ -18,7 +18,7 @@ _lib = None
 class PtoScene(C.Structure):
     _fields_ = [("num_triangles", C.c_int32), ("num_vertices", C.c_int32),
                 ("indices", C.c_void_p), ("vertices", C.c_void_p),
-                ("spheres", C.c_void_p), ("materials", C.c_void_p)]
+                ("spheres", C.c_void_p), ("materials", C.c_void_p), ("material_ids", C.c_void_p)]
 
 
 class PtoUniforms(C.Structure):
@@ -26,7 +26,7 @@ class PtoUniforms(C.Structure):
                 ("cam_hor", C.c_float * 3), ("cam_ver", C.c_float * 3),
                 ("num_triangles", C.c_int32), ("depth", C.c_int32),
                 ("width", C.c_int32), ("height", C.c_int32),
-                ("variant", C.c_int32), ("normal_mode", C.c_int32)]
+                ("variant", C.c_int32), ("normal_mode", C.c_int32), ("shading_mode", C.c_int32)]
 
 
 def build(force=False):
@@ -70,27 +70,56 @@ NORMALS_VERTEX, NORMALS_GEOMETRIC = 0, 1
 class Scene:
     """Host-side scene arrays in the reference's upload layouts (PathTracer.cpp:1253-1288)."""
 
-    def __init__(self, vertices=None, indices=None, spheres=None, materials=None):
+    def __init__(self, vertices=None, indices=None, spheres=None, materials=None, material_ids=None):
         self.vertices = np.ascontiguousarray(vertices if vertices is not None else np.zeros((1, 6)), np.float32).reshape(-1, 6)
         self.indices = np.ascontiguousarray(indices if indices is not None else np.zeros((0, 3)), np.uint32).reshape(-1, 3)
         self.spheres = np.ascontiguousarray(spheres if spheres is not None else np.zeros((10, 4)), np.float32).reshape(10, 4)
-        self.materials = np.ascontiguousarray(materials if materials is not None else np.zeros((10, 4)), np.float32).reshape(10, 4)
+        m = np.asarray(materials if materials is not None else np.zeros((10, 4)), np.float32).reshape(-1, 4)
+        if len(m) > 10:
+            raise ValueError("the reference's materials texture holds 10 entries")
+        self.materials = np.zeros((10, 4), np.float32)
+        self.materials[:len(m)] = m
         if self.indices.size and int(self.indices.max()) >= len(self.vertices):
             raise ValueError("triangle index out of range")
+        self.material_ids = np.ascontiguousarray(material_ids if material_ids is not None else np.zeros(len(self.indices)), np.int32)
+        if len(self.material_ids) != len(self.indices) or (self.material_ids.size and (self.material_ids.min() < 0 or self.material_ids.max() > 9)):
+            raise ValueError("material ids must be one per triangle, in 0..9")
 
     def c_struct(self):
         return PtoScene(len(self.indices), len(self.vertices), self.indices.ctypes.data, self.vertices.ctypes.data,
-                        self.spheres.ctypes.data, self.materials.ctypes.data)
+                        self.spheres.ctypes.data, self.materials.ctypes.data, self.material_ids.ctypes.data)
 
 
-def uniforms(camera12, width, height, num_triangles, depth=10, variant=VARIANT_MESH, normal_mode=NORMALS_VERTEX):
+SHADE_REFERENCE, SHADE_MATERIALS = 0, 1
+
+
+def uniforms(camera12, width, height, num_triangles, depth=10, variant=VARIANT_MESH, normal_mode=NORMALS_VERTEX,
+             shading_mode=SHADE_REFERENCE):
     cam = np.asarray(camera12, np.float32).reshape(12)
     u = PtoUniforms()
     for i in range(3):
         u.cam_pos[i], u.cam_llc[i], u.cam_hor[i], u.cam_ver[i] = cam[i], cam[3 + i], cam[6 + i], cam[9 + i]
     u.num_triangles, u.depth, u.width, u.height = num_triangles, depth, width, height
-    u.variant, u.normal_mode = variant, normal_mode
+    u.variant, u.normal_mode, u.shading_mode = variant, normal_mode, shading_mode
     return u
+
+
+def material_table_from_mtl(mat_values, unassigned=(0.5, 0.5, 0.5)):
+    """Build-defined rule that turns MTL statements into the (r, g, b, e) table of the "materials" shading mode:
+    emission = Ke, or Ka when Ke is zero and Ka exceeds 1 (the Cornell file's light is `Ka 20 20 20` and has no Ke);
+    an emitter is stored as (colour / peak, peak); everything else as (Kd, 0). One extra grey diffuse entry is
+    appended for triangles without a `usemtl`. mat_values: rows of Ka Kd Ks Kt Ke (3 each), ..."""
+    rows = []
+    for m in np.asarray(mat_values, np.float32).reshape(-1, 19):
+        ka, kd, ke = m[0:3], m[3:6], m[12:15]
+        em = ke if ke.max() > 0 else (ka if ka.max() > 1.0 else None)
+        if em is not None:
+            peak = np.float32(em.max())
+            rows.append([em[0] / peak, em[1] / peak, em[2] / peak, peak])
+        else:
+            rows.append([kd[0], kd[1], kd[2], 0.0])
+    rows.append([unassigned[0], unassigned[1], unassigned[2], 0.0])
+    return np.asarray(rows, np.float32)
 
 
 def camera(fov_deg, width, height, eye, target, up):

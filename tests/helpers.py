@@ -6,7 +6,13 @@ import numpy as np
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 CASES = ["monkey_mesh_128", "monkey_mesh_160x90", "monkey_mesh_1080p_crop", "world_128", "world_1280x720_crop",
-         "cornell_geo_128", "cornell_geo_1080p_crop", "suzanne_geo_96"]
+         "cornell_geo_128", "cornell_geo_1080p_crop", "suzanne_geo_96",
+         # build-defined diffuse/emissive mode: llvmpipe ran the reference shader with oracle/llvmpipe/edits/mesh_materials_geo.txt
+         "cornell_materials_128", "cornell_materials_1080p_crop"]
+
+
+def case_shading_mode(fx):
+    return int(fx["shading_mode"]) if "shading_mode" in fx else 0
 
 
 def load_case(name):

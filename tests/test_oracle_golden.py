@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import pt_oracle as po
-from helpers import CASES, GOLDEN, bits, load_case, n_bit_mismatch
+from helpers import CASES, GOLDEN, bits, case_shading_mode, load_case, n_bit_mismatch
 
 
 @pytest.mark.parametrize("kind,col", [("sin", 0), ("cos", 0), ("exp2", 1), ("pow", 2)])
@@ -41,8 +41,9 @@ def test_case_bit_exact(name):
     fx = load_case(name)
     W, H = int(fx["width"]), int(fx["height"])
     x0, y0, w, h = (int(v) for v in fx["crop"])
-    scene = po.Scene(fx["vertices"], fx["indices"], fx["spheres"], fx["materials"])
-    u = po.uniforms(fx["camera"], W, H, len(fx["indices"]), int(fx["depth"]), int(fx["variant"]), int(fx["normal_mode"]))
+    scene = po.Scene(fx["vertices"], fx["indices"], fx["spheres"], fx["materials"], fx.get("material_ids"))
+    u = po.uniforms(fx["camera"], W, H, len(fx["indices"]), int(fx["depth"]), int(fx["variant"]), int(fx["normal_mode"]),
+                    case_shading_mode(fx))
     ids, ts, rds = po.primary(scene, u, window=(x0, y0, w, h), threads=8)
     win = (slice(y0, y0 + h), slice(x0, x0 + w))
     assert np.array_equal(ids[win], fx["lp_id"])
