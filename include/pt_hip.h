@@ -70,6 +70,18 @@ typedef enum PtAccumMode {
                           produce before their sums are merged and divided by the sample count */
 } PtAccumMode;
 
+/* What Shade() does with a mesh hit. */
+typedef enum PtShadingMode {
+    PT_SHADE_REFERENCE = 0, /* the shader as committed: the fetched material is overwritten with 0.5 (pathtracing.fs:228-229),
+                               every surface is the same modified-Phong lobe, the ray origin never moves */
+    PT_SHADE_MATERIALS = 1  /* build-defined: the fetched material (r,g,b,e) is kept. e > 0: emitter of radiance rgb*e, the
+                               path ends; otherwise Lambert of albedo rgb, cosine-weighted about the normal with the shader's
+                               own GetTangentSpace/randomHemisphere (pathtracing.fs:44-76; the form of its commented lines
+                               :269-279), origin moved to the hit point (:274), emitted radiance added next to the sky term
+                               (:410). Mesh programs only. Its definition is the shader text with exactly these
+                               statements edited in; the tests compare against that text run by a GLSL implementation. */
+} PtShadingMode;
+
 /* The program's uniforms (pathtracing.fs:6-9,17-18), set per frame at PathTracer.cpp:1372-1382.
  * u_Samples (pathtracing.fs:19) is not here: it is the sample index that pt_dispatch() is given. */
 typedef struct PtUniforms {
@@ -137,6 +149,12 @@ PtStatus pt_upload_materials(PtContext* ctx, const float* rgbt, int32_t count);
 PtStatus pt_upload_mesh(PtContext* ctx, const float* vertices, int32_t num_vertices, const uint32_t* indices,
                         int32_t num_triangles);
 PtStatus pt_set_normal_mode(PtContext* ctx, PtNormalMode mode);
+/* One row index into the material table per triangle of the uploaded mesh (count must equal its triangle count; ids
+ * >= 0). This is tinyobj's mesh_t::material_ids (tiny_obj_loader.h:207), which the reference's loader fills and its host
+ * then drops: its shader returns 0.0 as the hit index of every triangle (pathtracing.fs:167). Used by
+ * PT_SHADE_MATERIALS only. A new pt_upload_mesh discards the ids. */
+PtStatus pt_upload_material_ids(PtContext* ctx, const int32_t* ids, int32_t count);
+PtStatus pt_set_shading_mode(PtContext* ctx, PtShadingMode mode);
 /* Builds a linear BVH over the uploaded mesh on the device (Morton codes, radix sort, Karras hierarchy, bottom-up
  * boxes). No counterpart in the reference, whose shader tests every triangle for every ray; needed for scenes beyond a
  * few thousand triangles. A new pt_upload_mesh discards it. Meshes of at most 4 triangles need none (PT_OK, no-op). */

@@ -17,6 +17,7 @@ PROGRAM_WORLD, PROGRAM_MESH = 0, 1
 NORMALS_VERTEX, NORMALS_GEOMETRIC = 0, 1
 ACCUM_MEAN, ACCUM_SUM = 0, 1
 ACCEL_AUTO, ACCEL_BRUTE, ACCEL_BVH, ACCEL_CULL = 0, 1, 2, 3
+SHADE_REFERENCE, SHADE_MATERIALS = 0, 1
 
 
 class PtUniforms(C.Structure):
@@ -52,6 +53,8 @@ SIGNATURES = {
     "pt_upload_materials": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "pt_upload_mesh": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),
     "pt_set_normal_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "pt_upload_material_ids": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "pt_set_shading_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "pt_build_accel": (C.c_int, [C.c_void_p]),
     "pt_set_accel_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "pt_target_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
@@ -164,6 +167,13 @@ class Tracer:
 
     def set_normal_mode(self, mode):
         check(self._lib.pt_set_normal_mode(self._ctx, mode), self._lib)
+
+    def upload_material_ids(self, ids):
+        a = np.ascontiguousarray(ids, np.int32).reshape(-1)
+        check(self._lib.pt_upload_material_ids(self._ctx, a.ctypes.data, len(a)), self._lib)
+
+    def set_shading_mode(self, mode):
+        check(self._lib.pt_set_shading_mode(self._ctx, mode), self._lib)
 
     # -- target
     def target_create(self, width, height):

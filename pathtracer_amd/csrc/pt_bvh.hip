@@ -149,7 +149,7 @@ __device__ __forceinline__ uint32_t traversal_ref(int ref, const int* __restrict
 __global__ __launch_bounds__(256) void bvh_emit_nodes(const unsigned long long* __restrict__ keys, const int* __restrict__ child,
                                                       const int* __restrict__ range, const float* __restrict__ tri_box,
                                                       const float* __restrict__ node_box, int n, float rox, float roy, float roz,
-                                                      float* __restrict__ nodes) {
+                                                      float extra_pad, float* __restrict__ nodes) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;
     const float ro[3] = {rox, roy, roz};
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void bvh_emit_nodes(const unsigned long long* 
             rel[3 + k] = box[3 + k] - ro[k];
             far = fmaxf(far, fmaxf(fabsf(rel[k]), fabsf(rel[3 + k])));
         }
-        const float pad = 1.0e-5f * far + 1.0e-30f;
+        const float pad = 1.0e-5f * far + extra_pad + 1.0e-30f;
         for (int k = 0; k < 3; ++k) {
             out[6 * c + k] = rel[k] - pad;
             out[6 * c + 3 + k] = rel[3 + k] + pad;
@@ -231,12 +231,19 @@ hipError_t pt_bvh_build_topology(const PtBvhBuild& b, hipStream_t stream, int32_
     return hipGetLastError();
 }
 
-hipError_t pt_bvh_emit(const PtBvhBuild& b, const float ro[3], const float* tris, hipStream_t stream) {
+hipError_t pt_bvh_emit(const PtBvhBuild& b, const float ro[3], const float* tris, const float* tris_abs, hipStream_t stream) {
     const int n = b.num_triangles;
     if (n < 1) return hipSuccess;
-    if (n >= 2)
+    if (n >= 2) {
         hipLaunchKernelGGL(bvh_emit_nodes, grid_for(n - 1), dim3(256), 0, stream, b.keys, b.child, b.range, b.tri_box, b.node_box, n, ro[0],
-                           ro[1], ro[2], b.nodes);
+                           ro[1], ro[2], 0.0f, b.nodes);
+        // Absolute boxes for rays that start anywhere in the scene: the slab arithmetic then errs relative to the
+        // larger of box and origin coordinates, so the pad also carries a term of the scene's size.
+        hipLaunchKernelGGL(bvh_emit_nodes, grid_for(n - 1), dim3(256), 0, stream, b.keys, b.child, b.range, b.tri_box, b.node_box, n, 0.0f,
+                           0.0f, 0.0f, 4.0e-6f * b.scene_scale, b.nodes_abs);
+    }
+    hipLaunchKernelGGL(bvh_gather_records, grid_for(n + PT_TRI_PAD), dim3(256), 0, stream, b.keys, reinterpret_cast<const float4*>(tris_abs), n,
+                       reinterpret_cast<float4*>(b.sorted_tris_abs), b.sorted_ids);
     hipLaunchKernelGGL(bvh_gather_records, grid_for(n + PT_TRI_PAD), dim3(256), 0, stream, b.keys, reinterpret_cast<const float4*>(tris), n,
                        reinterpret_cast<float4*>(b.sorted_tris), b.sorted_ids);
     return hipGetLastError();

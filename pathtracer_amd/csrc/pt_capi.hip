@@ -3,6 +3,8 @@
 #include "../../include/pt_hip.h"
 #include "pt_internal.h"
 
+#include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -61,6 +63,12 @@ struct PtContext {
     float* d_vnormals = nullptr;
     float* d_gnormals = nullptr;
     float* d_cull = nullptr;
+    float* d_tris_abs = nullptr;    // a, e1, e2 records (origin-independent)
+    int32_t* d_material_ids = nullptr;
+    int32_t num_material_ids = 0;
+    int32_t max_material_id = -1;
+    float mesh_extent = 0.f;        // largest absolute vertex coordinate
+    PtShadingMode shading_mode = PT_SHADE_REFERENCE;
     bool records_valid = false;
     float records_ro[3] = {0, 0, 0};
     // LBVH (optional)
@@ -148,7 +156,7 @@ void free_target(PtContext* ctx) {
 void free_bvh(PtContext* ctx) {
     PtBvhBuild& b = ctx->bvh;
     void* ptrs[] = {b.tri_box, b.scene_box, b.keys_tmp, b.keys, b.sort_tmp, b.child, b.range, b.node_box, b.done, b.remaining,
-                    b.nodes, b.sorted_tris, b.sorted_ids};
+                    b.nodes, b.sorted_tris, b.sorted_ids, b.nodes_abs, b.sorted_tris_abs};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     b = PtBvhBuild{};
@@ -157,13 +165,17 @@ void free_bvh(PtContext* ctx) {
 
 void free_mesh(PtContext* ctx) {
     free_bvh(ctx);
-    float** f[] = {&ctx->d_vertices, &ctx->d_tris, &ctx->d_vnormals, &ctx->d_gnormals, &ctx->d_cull};
+    float** f[] = {&ctx->d_vertices, &ctx->d_tris, &ctx->d_vnormals, &ctx->d_gnormals, &ctx->d_cull, &ctx->d_tris_abs};
     for (float** q : f) {
         if (*q) (void)hipFree(*q);
         *q = nullptr;
     }
     if (ctx->d_indices) (void)hipFree(ctx->d_indices);
     ctx->d_indices = nullptr;
+    if (ctx->d_material_ids) (void)hipFree(ctx->d_material_ids);
+    ctx->d_material_ids = nullptr;
+    ctx->num_material_ids = 0;
+    ctx->max_material_id = -1;
     ctx->num_vertices = ctx->num_triangles = 0;
     ctx->records_valid = false;
 }
@@ -173,9 +185,13 @@ PtStatus ensure_records(PtContext* ctx) {
     const float* ro = ctx->uniforms.camera_position;
     if (ctx->records_valid && memcmp(ro, ctx->records_ro, sizeof ctx->records_ro) == 0) return PT_OK;
     PT_HIP_TRY(pt_launch_prepare_triangles(ctx->d_vertices, ctx->d_indices, ctx->num_triangles, ro, ctx->d_tris,
-                                           ctx->d_vnormals, ctx->d_gnormals, ctx->d_cull, ctx->stream));
+                                           ctx->d_vnormals, ctx->d_gnormals, ctx->d_cull, ctx->d_tris_abs, ctx->stream));
     // the BVH's boxes and leaf-order records are expressed relative to the ray origin too
-    if (ctx->bvh_built) PT_HIP_TRY(pt_bvh_emit(ctx->bvh, ro, ctx->d_tris, ctx->stream));
+    if (ctx->bvh_built) {
+        // absolute-box variant: its padding scales with the largest coordinate a ray origin or a box can have
+        ctx->bvh.scene_scale = std::max(ctx->mesh_extent, std::max(std::fabs(ro[0]), std::max(std::fabs(ro[1]), std::fabs(ro[2]))));
+        PT_HIP_TRY(pt_bvh_emit(ctx->bvh, ro, ctx->d_tris, ctx->d_tris_abs, ctx->stream));
+    }
     memcpy(ctx->records_ro, ro, sizeof ctx->records_ro);
     ctx->records_valid = true;
     return PT_OK;
@@ -219,7 +235,24 @@ PtStatus fill_params(PtContext* ctx, PtKernelParams* p, const Program** prog_out
                              (ctx->accel_mode == PT_ACCEL_BVH || u.num_triangles > PT_BVH_AUTO_MIN_TRIANGLES);
         PT_REQUIRE(use_bvh || ctx->accel_mode != PT_ACCEL_BVH, PT_ERR_STATE, "the BVH covers all %d triangles but u_NumTriangles = %d",
                    ctx->num_triangles, u.num_triangles);
-        if (use_bvh) {
+        p->shading_mode = (int32_t)ctx->shading_mode;
+        if (ctx->shading_mode == PT_SHADE_MATERIALS) {
+            PT_REQUIRE(ctx->accel_mode != PT_ACCEL_CULL, PT_ERR_STATE, "PT_ACCEL_CULL serves rays from the camera only; PT_SHADE_MATERIALS moves the origin");
+            PT_REQUIRE(ctx->d_materials != nullptr, PT_ERR_STATE, "PT_SHADE_MATERIALS but no material table: call pt_upload_materials first");
+            PT_REQUIRE(ctx->num_material_ids == ctx->num_triangles, PT_ERR_STATE,
+                       "PT_SHADE_MATERIALS needs one material id per triangle: %d ids for %d triangles (call pt_upload_material_ids after pt_upload_mesh)",
+                       ctx->num_material_ids, ctx->num_triangles);
+            PT_REQUIRE(ctx->max_material_id < ctx->num_materials, PT_ERR_STATE, "material id %d but the table has %d rows",
+                       ctx->max_material_id, ctx->num_materials);
+            p->tris_abs = ctx->d_tris_abs;
+            p->materials = ctx->d_materials;
+            p->material_ids = ctx->d_material_ids;
+            if (use_bvh) {
+                p->bvh_nodes_abs = ctx->bvh.nodes_abs;
+                p->bvh_tris_abs = ctx->bvh.sorted_tris_abs;
+                p->bvh_ids = ctx->bvh.sorted_ids;
+            }
+        } else if (use_bvh) {
             p->bvh_nodes = ctx->bvh.nodes;
             p->bvh_tris = ctx->bvh.sorted_tris;
             p->bvh_ids = ctx->bvh.sorted_ids;
@@ -393,12 +426,51 @@ PtStatus pt_upload_mesh(PtContext* ctx, const float* vertices, int32_t num_verti
     PT_HIP_TRY(hipMalloc(&ctx->d_vnormals, nt * 9 * sizeof(float)));
     PT_HIP_TRY(hipMalloc(&ctx->d_gnormals, nt * 3 * sizeof(float)));
     PT_HIP_TRY(hipMalloc(&ctx->d_cull, nt * PT_CULL_FLOATS * sizeof(float)));
+    PT_HIP_TRY(hipMalloc(&ctx->d_tris_abs, (nt + PT_TRI_PAD) * PT_TRI_FLOATS * sizeof(float)));
+    PT_HIP_TRY(hipMemsetAsync(ctx->d_tris_abs + nt * PT_TRI_FLOATS, 0, PT_TRI_PAD * PT_TRI_FLOATS * sizeof(float), ctx->stream));
     PT_HIP_TRY(hipMemcpyAsync(ctx->d_vertices, vertices, (size_t)num_vertices * 6 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     PT_HIP_TRY(hipMemcpyAsync(ctx->d_indices, indices, nt * 3 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->num_vertices = num_vertices;
     ctx->num_triangles = num_triangles;
     ctx->records_valid = false;
+    float extent = 0.f;
+    for (size_t v = 0; v < (size_t)num_vertices; ++v)
+        for (int k = 0; k < 3; ++k) {
+            const float c = std::fabs(vertices[6 * v + k]);
+            if (c > extent && c < 3.0e38f) extent = c;
+        }
+    ctx->mesh_extent = extent;
+    return PT_OK;
+}
+
+PtStatus pt_upload_material_ids(PtContext* ctx, const int32_t* ids, int32_t count) {
+    PtStatus s = bind(ctx);
+    if (s != PT_OK) return s;
+    PT_REQUIRE(ids != nullptr, PT_ERR_INVALID_ARGUMENT, "ids is null");
+    PT_REQUIRE(ctx->num_triangles > 0, PT_ERR_STATE, "no mesh uploaded: material ids belong to the triangles of pt_upload_mesh");
+    PT_REQUIRE(count == ctx->num_triangles, PT_ERR_INVALID_ARGUMENT, "%d material ids for %d triangles", count, ctx->num_triangles);
+    int32_t top = -1;
+    for (int32_t i = 0; i < count; ++i) {
+        PT_REQUIRE(ids[i] >= 0, PT_ERR_INVALID_ARGUMENT, "material id %d of triangle %d is negative (map 'no material' to a table row)", ids[i], i);
+        if (ids[i] > top) top = ids[i];
+    }
+    PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->d_material_ids) (void)hipFree(ctx->d_material_ids);
+    ctx->d_material_ids = nullptr;
+    ctx->num_material_ids = 0;
+    PT_HIP_TRY(hipMalloc(&ctx->d_material_ids, (size_t)count * sizeof(int32_t)));
+    PT_HIP_TRY(hipMemcpyAsync(ctx->d_material_ids, ids, (size_t)count * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->num_material_ids = count;
+    ctx->max_material_id = top;
+    return PT_OK;
+}
+
+PtStatus pt_set_shading_mode(PtContext* ctx, PtShadingMode mode) {
+    PT_REQUIRE(ctx != nullptr, PT_ERR_INVALID_ARGUMENT, "null context");
+    PT_REQUIRE(mode == PT_SHADE_REFERENCE || mode == PT_SHADE_MATERIALS, PT_ERR_INVALID_ARGUMENT, "unknown shading mode %d", (int)mode);
+    ctx->shading_mode = mode;
     return PT_OK;
 }
 
@@ -433,6 +505,8 @@ PtStatus pt_build_accel(PtContext* ctx) {
     alloc(&b.nodes, ni * PT_BVH_NODE_FLOATS * sizeof(float));
     alloc(&b.sorted_tris, (nn + PT_TRI_PAD) * PT_TRI_FLOATS * sizeof(float));
     alloc(&b.sorted_ids, (nn + PT_TRI_PAD) * sizeof(int));
+    alloc(&b.nodes_abs, ni * PT_BVH_NODE_FLOATS * sizeof(float));
+    alloc(&b.sorted_tris_abs, (nn + PT_TRI_PAD) * PT_TRI_FLOATS * sizeof(float));
     if (e == hipSuccess) e = pt_bvh_build_topology(b, ctx->stream, &ctx->bvh_refit_passes);
     if (e != hipSuccess) {
         free_bvh(ctx);

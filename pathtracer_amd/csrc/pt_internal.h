@@ -37,6 +37,7 @@ struct PtTriRecordLayout {
 
 struct PtBvhBuild {
     int32_t num_triangles;
+    float scene_scale;            // largest absolute vertex coordinate (host-computed at upload)
     const float* vertices;        // raw upload (6 floats per vertex)
     const uint32_t* indices;      // raw upload
     float* tri_box;               // n x 6, absolute, original triangle order
@@ -51,6 +52,8 @@ struct PtBvhBuild {
     int* done;                    // (n-1): refit sweep in which the node was finished
     int* remaining;               // 1
     float* nodes;                 // (n-1) x PT_BVH_NODE_FLOATS traversal records
+    float* nodes_abs;             // (n-1) x PT_BVH_NODE_FLOATS, absolute boxes
+    float* sorted_tris_abs;       // (n + PT_TRI_PAD) x PT_TRI_FLOATS: a, e1, e2 in leaf order
     float* sorted_tris;           // (n + PT_TRI_PAD) x PT_TRI_FLOATS
     int* sorted_ids;              // n + PT_TRI_PAD
 };
@@ -59,7 +62,7 @@ size_t pt_bvh_sort_temp_bytes(int32_t n);
 // Morton codes, sort, hierarchy, boxes. Synchronises the stream (a handful of times) to learn when the refit is done.
 hipError_t pt_bvh_build_topology(const PtBvhBuild& b, hipStream_t stream, int32_t* out_passes);
 // Traversal records for ray origin `ro` + triangle records/ids in leaf order (from the per-triangle records `tris`).
-hipError_t pt_bvh_emit(const PtBvhBuild& b, const float ro[3], const float* tris, hipStream_t stream);
+hipError_t pt_bvh_emit(const PtBvhBuild& b, const float ro[3], const float* tris, const float* tris_abs, hipStream_t stream);
 
 // Work unit of the render kernels: one workgroup renders a PT_TILE_DIM x PT_TILE_DIM pixel tile with PT_TILE_WAVES waves
 // (each wave an 8x8 block of it). With PT_TILE_WAVES = 1 every wave is its own workgroup: waves share nothing, and a
@@ -90,9 +93,15 @@ struct PtKernelParams {
     const float* vnormals;              // num_triangles x 9: the three vertex normals (na, nb, nc)
     const float* gnormals;              // num_triangles x 3: normalize(cross(e1, e2))
     const float* cull;                  // num_triangles x PT_CULL_FLOATS, or null = no wave-level culling
+    const float* tris_abs;              // num_triangles x PT_TRI_FLOATS: a, e1, e2 (for rays with their own origin)
+    const float* materials;             // num_materials x (r, g, b, e)
+    const int32_t* material_ids;        // per triangle
+    int32_t shading_mode;               // PtShadingMode
     const float* bvh_nodes;             // LBVH traversal records, or null = test every triangle in index order
     const float* bvh_tris;              // triangle records in leaf order
     const int32_t* bvh_ids;             // triangle id of each leaf-order record
+    const float* bvh_nodes_abs;         // LBVH records with absolute boxes (rays with their own origin)
+    const float* bvh_tris_abs;          // a, e1, e2 records in leaf order
     const float* spheres;               // 10 x (cx, cy, cz, r)
     const float* src;                   // RGBA32F image read (previous result)
     float* dst;                         // RGBA32F image written
@@ -106,7 +115,7 @@ struct PtKernelParams {
 // Launchers (defined in pt_kernels.hip). All are asynchronous on `stream`.
 hipError_t pt_launch_prepare_triangles(const float* vertices, const uint32_t* indices, int32_t num_triangles,
                                        const float ro[3], float* tris, float* vnormals, float* gnormals, float* cull,
-                                       hipStream_t stream);
+                                       float* tris_abs, hipStream_t stream);
 hipError_t pt_launch_fill_rgba(float* img, size_t num_pixels, float r, float g, float b, float a, hipStream_t stream);
 hipError_t pt_launch_render(const PtKernelParams& p, int program_kind, hipStream_t stream);
 hipError_t pt_launch_present(const float* img, size_t num_pixels, uint32_t* out_rgba8, hipStream_t stream);

@@ -149,6 +149,32 @@ __device__ __forceinline__ void test_triangle(const TriRec& t, int id, v3 rd, Hi
     }
 }
 
+// The same test for a ray with its own origin (the "materials" shading mode moves the origin to each hit point, as the
+// shader's commented line fs:274 does): fs:136-168 as written, from a record that holds a, e1, e2 and the triangle's
+// material id:  a.xyz e1.x | e1.yz e2.xy | e2.z matid - - | -
+template <bool ANY_ORDER>
+__device__ __forceinline__ void test_triangle_from(const TriRec& t, int id, v3 ro, v3 rd, Hit& h) {
+    const v3 a = V(t.a.x, t.a.y, t.a.z);
+    const v3 e1 = V(t.a.w, t.b.x, t.b.y);
+    const v3 e2 = V(t.b.z, t.b.w, t.c.x);
+    const v3 q = cross3(rd, e2);
+    const float det = dot3(e1, q);
+    if (!__builtin_amdgcn_ballot_w64(det >= 0.0001f)) return;
+    const v3 ap = ro - a;
+    const v3 r = cross3(ap, e1);
+    const float u = dot3(ap, q);
+    const float v = dot3(rd, r);
+    const bool inside = (det >= 0.0001f) & (u >= 0.0f) & (v >= 0.0f) & ((u + v) <= det);
+    if (inside) {
+        const float ood = 1.0f / det;
+        const float tt = dot3(e2, r) * ood;
+        const bool closer = ANY_ORDER ? (tt < h.t || (tt == h.t && id < h.id)) : (tt < h.t);
+        if (tt > 0.0f && closer) {
+            h.t = tt; h.id = id; h.u = u; h.v = v; h.ood = ood;
+        }
+    }
+}
+
 __device__ __forceinline__ TriRec load_rec(const float4* __restrict__ recs, int i) {
     TriRec t;
     t.a = recs[4 * i]; t.b = recs[4 * i + 1]; t.c = recs[4 * i + 2]; t.d = recs[4 * i + 3];
@@ -177,6 +203,24 @@ __device__ __forceinline__ Hit intersect_mesh(const float* __restrict__ tris, in
         test_triangle<false>(b1, i + 3, rd, h);
     }
 #endif
+    return h;
+}
+
+// fs:125-174 for rays with their own origins: same double-buffered scalar record stream.
+__device__ __forceinline__ Hit intersect_mesh_from(const float* __restrict__ tris_abs, int n, v3 ro, v3 rd) {
+    Hit h;
+    h.t = 1.0e38f; h.id = -1; h.u = 0.f; h.v = 0.f; h.ood = 0.f;
+    const float4* __restrict__ recs = reinterpret_cast<const float4*>(tris_abs);
+    TriRec a0 = load_rec(recs, 0), a1 = load_rec(recs, 1);
+    for (int i = 0; i < n; i += 4) {
+        const TriRec b0 = load_rec(recs, i + 2), b1 = load_rec(recs, i + 3);
+        test_triangle_from<false>(a0, i, ro, rd, h);
+        test_triangle_from<false>(a1, i + 1, ro, rd, h);
+        a0 = load_rec(recs, i + 4);
+        a1 = load_rec(recs, i + 5);
+        test_triangle_from<false>(b0, i + 2, ro, rd, h);
+        test_triangle_from<false>(b1, i + 3, ro, rd, h);
+    }
     return h;
 }
 
@@ -275,7 +319,9 @@ __device__ __forceinline__ Hit intersect_mesh_culled(const PtKernelParams& p, v3
 // their paths through the tree is short. A lane's box test passes when its ray can reach the padded box no farther than
 // its current hit (equal distance included, so a lower-id triangle at the same distance is still found); leaves run
 // the exact triangle test with the explicit lowest-id rule. The result equals the all-triangles loop bit for bit.
-__device__ __forceinline__ Hit intersect_bvh(const PtKernelParams& p, v3 rd, uint32_t* __restrict__ stack, unsigned& node_visits,
+// MOVING = rays carry their own origin `ro` (boxes are then absolute and the origin is subtracted per lane).
+template <bool MOVING>
+__device__ __forceinline__ Hit intersect_bvh(const PtKernelParams& p, v3 ro, v3 rd, uint32_t* __restrict__ stack, unsigned& node_visits,
                                              unsigned& tri_tests) {
     Hit h;
     h.t = 1.0e38f; h.id = -1; h.u = 0.f; h.v = 0.f; h.ood = 0.f;
@@ -286,14 +332,18 @@ __device__ __forceinline__ Hit intersect_bvh(const PtKernelParams& p, v3 rd, uin
     const float ix = __builtin_amdgcn_rcpf(__builtin_fabsf(rd.x) > tiny ? rd.x : __builtin_copysignf(tiny, rd.x));
     const float iy = __builtin_amdgcn_rcpf(__builtin_fabsf(rd.y) > tiny ? rd.y : __builtin_copysignf(tiny, rd.y));
     const float iz = __builtin_amdgcn_rcpf(__builtin_fabsf(rd.z) > tiny ? rd.z : __builtin_copysignf(tiny, rd.z));
-    const float4* __restrict__ nodes = reinterpret_cast<const float4*>(p.bvh_nodes);
-    const float4* __restrict__ recs = reinterpret_cast<const float4*>(p.bvh_tris);
+    const float4* __restrict__ nodes = reinterpret_cast<const float4*>(MOVING ? p.bvh_nodes_abs : p.bvh_nodes);
+    const float4* __restrict__ recs = reinterpret_cast<const float4*>(MOVING ? p.bvh_tris_abs : p.bvh_tris);
+    const float ox = MOVING ? ro.x : 0.f, oy = MOVING ? ro.y : 0.f, oz = MOVING ? ro.z : 0.f;
     uint32_t ref = 0;  // root = internal node 0
     int sp = 0;
     for (;;) {
         if (ref & 0x80000000u) {
             const int first = (int)((ref & 0x7fffffffu) >> 3), count = (int)(ref & 7u) + 1;
-            for (int k = 0; k < count; ++k) test_triangle<true>(load_rec(recs, first + k), p.bvh_ids[first + k], rd, h);
+            for (int k = 0; k < count; ++k) {
+                if (MOVING) test_triangle_from<true>(load_rec(recs, first + k), p.bvh_ids[first + k], ro, rd, h);
+                else test_triangle<true>(load_rec(recs, first + k), p.bvh_ids[first + k], rd, h);
+            }
             tri_tests += (unsigned)count;
         } else {
             ++node_visits;
@@ -302,12 +352,12 @@ __device__ __forceinline__ Hit intersect_bvh(const PtKernelParams& p, v3 rd, uin
             const float limit = h.t * 1.0001f;
             // left box: n0.xyz = min, (n0.w, n1.x, n1.y) = max; right box: (n1.z, n1.w, n2.x) = min, n2.yzw = max
             float a, b;
-            a = n0.x * ix; b = n0.w * ix; float lnear = __builtin_fminf(a, b), lfar = __builtin_fmaxf(a, b);
-            a = n0.y * iy; b = n1.x * iy; lnear = __builtin_fmaxf(lnear, __builtin_fminf(a, b)); lfar = __builtin_fminf(lfar, __builtin_fmaxf(a, b));
-            a = n0.z * iz; b = n1.y * iz; lnear = __builtin_fmaxf(lnear, __builtin_fminf(a, b)); lfar = __builtin_fminf(lfar, __builtin_fmaxf(a, b));
-            a = n1.z * ix; b = n2.y * ix; float rnear = __builtin_fminf(a, b), rfar = __builtin_fmaxf(a, b);
-            a = n1.w * iy; b = n2.z * iy; rnear = __builtin_fmaxf(rnear, __builtin_fminf(a, b)); rfar = __builtin_fminf(rfar, __builtin_fmaxf(a, b));
-            a = n2.x * iz; b = n2.w * iz; rnear = __builtin_fmaxf(rnear, __builtin_fminf(a, b)); rfar = __builtin_fminf(rfar, __builtin_fmaxf(a, b));
+            a = (n0.x - ox) * ix; b = (n0.w - ox) * ix; float lnear = __builtin_fminf(a, b), lfar = __builtin_fmaxf(a, b);
+            a = (n0.y - oy) * iy; b = (n1.x - oy) * iy; lnear = __builtin_fmaxf(lnear, __builtin_fminf(a, b)); lfar = __builtin_fminf(lfar, __builtin_fmaxf(a, b));
+            a = (n0.z - oz) * iz; b = (n1.y - oz) * iz; lnear = __builtin_fmaxf(lnear, __builtin_fminf(a, b)); lfar = __builtin_fminf(lfar, __builtin_fmaxf(a, b));
+            a = (n1.z - ox) * ix; b = (n2.y - ox) * ix; float rnear = __builtin_fminf(a, b), rfar = __builtin_fmaxf(a, b);
+            a = (n1.w - oy) * iy; b = (n2.z - oy) * iy; rnear = __builtin_fmaxf(rnear, __builtin_fminf(a, b)); rfar = __builtin_fminf(rfar, __builtin_fmaxf(a, b));
+            a = (n2.x - oz) * iz; b = (n2.w - oz) * iz; rnear = __builtin_fmaxf(rnear, __builtin_fminf(a, b)); rfar = __builtin_fminf(rfar, __builtin_fmaxf(a, b));
             const bool hl = (lnear <= lfar) & (lfar >= 0.0f) & (lnear <= limit);
             const bool hr = (rnear <= rfar) & (rfar >= 0.0f) & (rnear <= limit);
             const unsigned long long ml = __builtin_amdgcn_ballot_w64(hl), mr = __builtin_amdgcn_ballot_w64(hr);
@@ -404,6 +454,33 @@ __device__ __forceinline__ int tile_of_block(const PtKernelParams& p) {
     return p.tile_order ? (int)p.tile_order[blockIdx.x] : (int)blockIdx.x;
 }
 
+// Shade() of the build-defined diffuse/emissive mode (the reference's live Shade ignores materials; its Lambert and
+// emissive code is only present as comments, fs:269-279, 317-358). material = (r, g, b, e): e > 0 is an emitter of
+// radiance rgb*e that ends the path; otherwise a Lambert surface of albedo rgb: cosine-weighted direction about N from
+// the shader's own GetTangentSpace / randomHemisphere(r1, 1.0) (fs:44-76) with its own rand01(), and the origin moves
+// to the hit point as in fs:274. Pinned against llvmpipe running the shader with exactly these statements edited in.
+__device__ __forceinline__ void shade_materials(Rng& rng, const float* __restrict__ materials, int mat, v3& energy, v3& emitted, v3& ro,
+                                                v3& rd, v3 P, v3 N) {
+    const float4 m = reinterpret_cast<const float4*>(materials)[mat];
+    if (m.w > 0.0f) {
+        emitted = V(energy.x * (m.x * m.w), energy.y * (m.y * m.w), energy.z * (m.z * m.w));
+        energy = V(0.f, 0.f, 0.f);
+        return;
+    }
+    const float r1 = rng.rand01();
+    v3 helper = V(1.0f, 0.0f, 0.0f);
+    if (__builtin_fabsf(N.x) > 0.99f) helper = V(0.0f, 0.0f, 1.0f);
+    const v3 tangent = normalize3(cross3(N, helper));
+    const v3 binormal = normalize3(cross3(N, tangent));
+    const float cos_t = lp_pow(r1, 1.0f / (1.0f + 1.0f));
+    const float sin_t = __builtin_sqrtf(__builtin_fmaxf(0.0f, 1.0f - cos_t * cos_t));
+    const float phi = (rng.rand01() * 2.0f) * 3.141592653589f;
+    const v3 hemi = V(lp_sincos<true>(phi) * sin_t, cos_t, lp_sincos<false>(phi) * sin_t);
+    rd = (tangent * hemi.x + N * hemi.y) + binormal * hemi.z;
+    ro = P + rd * 0.0001f;
+    energy = V(energy.x * m.x, energy.y * m.y, energy.z * m.z);
+}
+
 __device__ __forceinline__ bool pixel_of_lane(const PtKernelParams& p, int tile, int& x, int& y) {
     // a wave covers an 8x8 pixel block; the workgroup's PT_TILE_WAVES waves tile a PT_TILE_DIM square
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -441,14 +518,17 @@ __device__ __forceinline__ unsigned __reduce_max_trips(unsigned v) {
     return v;
 }
 
-template <int KIND>  // PtProgramKind
+// KIND: 0 sphere scene, 1 all-triangles loop, 2 LBVH, 3 culled loop. MATERIALS: false = the reference's shading (Phong
+// lobe, grey throughput, origin fixed at the camera), true = the diffuse/emissive mode (coloured throughput, emitted
+// radiance, origin moves to each hit point, so the ray-origin-specific triangle records cannot be used).
+template <int KIND, bool MATERIALS>
 __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKernelParams p) {
     __shared__ uint32_t s_stack[KIND == 2 ? PT_TILE_WAVES : 1][KIND == 2 ? PT_BVH_STACK : 1];
     int x, y;
     const int tile = tile_of_block(p);
     const bool in_window = pixel_of_lane(p, tile, x, y);
     const size_t pix = in_window ? ((size_t)y * p.width + x) : 0;
-    const v3 ro = V(p.ro[0], p.ro[1], p.ro[2]);
+    const v3 ro0 = V(p.ro[0], p.ro[1], p.ro[2]);
 
     Rng rng;
     rng.fcx = (float)x + 0.5f;
@@ -466,8 +546,9 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
     unsigned node_visits = 0, tri_tests = 0;  // per WAVE (the BVH walk is wave-uniform): records fetched
 
     // path state
-    v3 rd = rd0;
-    float energy = 1.0f;
+    v3 ro = ro0, rd = rd0;
+    v3 energy = V(1.0f, 1.0f, 1.0f);      // the reference mode keeps the three channels equal and only uses .x
+    v3 emitted = V(0.f, 0.f, 0.f);
     int level = 0;
     rng.samples = (float)sample;
     rng.sx = 0.0f;
@@ -482,8 +563,8 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
         Hit h;
         v3 N = V(0.f, 0.f, 0.f);
         if (KIND == 0) h = intersect_world(p.spheres, ro, rd, N);
-        else if (KIND == 1) h = intersect_mesh(p.tris, p.num_triangles, rd);
-        else if (KIND == 2) h = intersect_bvh(p, rd, s_stack[threadIdx.x >> 6], node_visits, tri_tests);
+        else if (KIND == 1) h = MATERIALS ? intersect_mesh_from(p.tris_abs, p.num_triangles, ro, rd) : intersect_mesh(p.tris, p.num_triangles, rd);
+        else if (KIND == 2) h = intersect_bvh<MATERIALS>(p, ro, rd, s_stack[threadIdx.x >> 6], node_visits, tri_tests);
         else h = intersect_mesh_culled(p, rd, active, cull0, tri_tests);
         ++trips;
         if (KIND == 3 && !active) continue;
@@ -491,15 +572,23 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
         const bool hit = h.id >= 0;
         if (hit) {
             if (KIND != 0) N = mesh_normal(p, h);
-            shade(rng, energy, rd, N);
+            if (MATERIALS) {
+                const v3 P = ro + rd * h.t;  // recPoint, fs:163
+                shade_materials(rng, p.materials, p.material_ids[h.id], energy, emitted, ro, rd, P, N);
+            } else {
+                shade(rng, energy.x, rd, N);
+            }
         }
         ++level;
         // fs:402 and the loop bound fs:388
-        if (!hit || energy == 0.0f || level >= p.depth) {
+        const bool spent = MATERIALS ? (energy.x == 0.0f && energy.y == 0.0f && energy.z == 0.0f) : energy.x == 0.0f;
+        if (!hit || spent || level >= p.depth) {
             // fs:408-415
             const float t = 0.5f * (rd.y + 1.0f);
             const float omt = 1.0f - t;
-            const float sr = energy * (omt + 0.5f * t), sg = energy * (omt + 0.7f * t), sb = energy * (omt + 1.0f * t);
+            const float ex = energy.x, ey = MATERIALS ? energy.y : energy.x, ez = MATERIALS ? energy.z : energy.x;
+            float sr = ex * (omt + 0.5f * t), sg = ey * (omt + 0.7f * t), sb = ez * (omt + 1.0f * t);
+            if (MATERIALS) { sr = sr + emitted.x; sg = sg + emitted.y; sb = sb + emitted.z; }
             if (p.accum_mode == 0) {
                 const float a = 1.0f / rng.samples;
                 mr = mr + a * (sr - mr);
@@ -510,7 +599,7 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
             }
             --remaining;
             sample += p.sample_stride;
-            rd = rd0; energy = 1.0f; level = 0;
+            ro = ro0; rd = rd0; energy = V(1.0f, 1.0f, 1.0f); emitted = V(0.f, 0.f, 0.f); level = 0;
             rng.samples = (float)sample;
             rng.sx = 0.0f;
         }
@@ -546,7 +635,7 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_primary_kernel(const PtKer
     if (KIND == 0) h = intersect_world(p.spheres, ro, rd, N);
     else if (KIND == 1) h = intersect_mesh(p.tris, p.num_triangles, rd);
     unsigned nv = 0, tt = 0;
-    if (KIND == 2) h = intersect_bvh(p, rd, s_stack[threadIdx.x >> 6], nv, tt);
+    if (KIND == 2) h = intersect_bvh<false>(p, ro, rd, s_stack[threadIdx.x >> 6], nv, tt);
     if (KIND == 3) h = intersect_mesh_culled(p, rd, in_window, load_cull(reinterpret_cast<const float4*>(p.cull), threadIdx.x & 63, p.num_triangles), tt);
     if (!in_window) return;
     if (p.out_ids) p.out_ids[pix] = h.id;
@@ -558,7 +647,8 @@ __global__ __launch_bounds__(256) void pt_prepare_triangles_kernel(const float* 
                                                                     const uint32_t* __restrict__ indices, int n,
                                                                     float rox, float roy, float roz,
                                                                     float* __restrict__ tris, float* __restrict__ vnormals,
-                                                                    float* __restrict__ gnormals, float* __restrict__ cull) {
+                                                                    float* __restrict__ gnormals, float* __restrict__ cull,
+                                                                    float* __restrict__ tris_abs) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float* pa = vertices + 6 * (size_t)indices[3 * i];
@@ -575,6 +665,12 @@ __global__ __launch_bounds__(256) void pt_prepare_triangles_kernel(const float* 
     t[9] = r.x; t[10] = r.y; t[11] = r.z;
     t[12] = dot3(e2, r);
     t[13] = 0.f; t[14] = 0.f; t[15] = 0.f;
+    // origin-independent record for rays with their own origins: a, e1, e2
+    float* ta = tris_abs + (size_t)i * PT_TRI_FLOATS;
+    ta[0] = a.x; ta[1] = a.y; ta[2] = a.z;
+    ta[3] = e1.x; ta[4] = e1.y; ta[5] = e1.z;
+    ta[6] = e2.x; ta[7] = e2.y; ta[8] = e2.z;
+    for (int k = 9; k < 16; ++k) ta[k] = 0.f;
     float* vn = vnormals + (size_t)i * 9;
     vn[0] = pa[3]; vn[1] = pa[4]; vn[2] = pa[5];
     vn[3] = pb[3]; vn[4] = pb[4]; vn[5] = pb[5];
@@ -669,10 +765,10 @@ int window_tiles(const PtKernelParams& p) { return PT_TILES_ACROSS(p.win_w) * PT
 
 hipError_t pt_launch_prepare_triangles(const float* vertices, const uint32_t* indices, int32_t num_triangles,
                                        const float ro[3], float* tris, float* vnormals, float* gnormals, float* cull,
-                                       hipStream_t stream) {
+                                       float* tris_abs, hipStream_t stream) {
     if (num_triangles <= 0) return hipSuccess;
     hipLaunchKernelGGL(pt_prepare_triangles_kernel, dim3((num_triangles + 255) / 256), dim3(256), 0, stream, vertices,
-                       indices, num_triangles, ro[0], ro[1], ro[2], tris, vnormals, gnormals, cull);
+                       indices, num_triangles, ro[0], ro[1], ro[2], tris, vnormals, gnormals, cull, tris_abs);
     return hipGetLastError();
 }
 
@@ -700,10 +796,15 @@ hipError_t pt_launch_schedule_tiles(uint32_t* tile_cost, uint32_t* tile_order, i
 
 hipError_t pt_launch_render(const PtKernelParams& p, int program_kind, hipStream_t stream) {
     if (p.win_w <= 0 || p.win_h <= 0 || p.num_samples <= 0) return hipSuccess;
-    if (program_kind == 0) hipLaunchKernelGGL(pt_render_kernel<0>, dim3(window_tiles(p)), dim3(PT_TILE_THREADS), 0, stream, p);
-    else if (p.bvh_nodes) hipLaunchKernelGGL(pt_render_kernel<2>, dim3(window_tiles(p)), dim3(PT_TILE_THREADS), 0, stream, p);
-    else if (p.cull) hipLaunchKernelGGL(pt_render_kernel<3>, dim3(window_tiles(p)), dim3(PT_TILE_THREADS), 0, stream, p);
-    else hipLaunchKernelGGL(pt_render_kernel<1>, dim3(window_tiles(p)), dim3(PT_TILE_THREADS), 0, stream, p);
+    const dim3 grid(window_tiles(p)), block(PT_TILE_THREADS);
+    if (program_kind == 0) hipLaunchKernelGGL((pt_render_kernel<0, false>), grid, block, 0, stream, p);
+    else if (p.shading_mode == 1) {
+        if (p.bvh_nodes_abs) hipLaunchKernelGGL((pt_render_kernel<2, true>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((pt_render_kernel<1, true>), grid, block, 0, stream, p);
+    }
+    else if (p.bvh_nodes) hipLaunchKernelGGL((pt_render_kernel<2, false>), grid, block, 0, stream, p);
+    else if (p.cull) hipLaunchKernelGGL((pt_render_kernel<3, false>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((pt_render_kernel<1, false>), grid, block, 0, stream, p);
     return hipGetLastError();
 }
 

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import pt_oracle as po
-from helpers import CASES, load_case, n_bit_mismatch
+from helpers import CASES, case_shading_mode, load_case, n_bit_mismatch
 
 pytestmark = pytest.mark.gpu
 
@@ -27,6 +27,10 @@ def setup_case(t, fx):
     t.upload_materials(fx["materials"])
     t.upload_mesh(fx["vertices"], fx["indices"])
     t.set_normal_mode(int(fx["normal_mode"]))
+    t.set_shading_mode(case_shading_mode(fx))
+    if case_shading_mode(fx):
+        t.upload_material_ids(fx["material_ids"])
+    t.set_accel_mode(0)
     t.set_accum_mode(0)
     t.target_create(W, H)
     t.set_uniforms(fx["camera"], len(fx["indices"]), int(fx["depth"]))
@@ -73,6 +77,98 @@ def test_multi_sample_dispatch_equals_frame_by_frame(tracer, name):
     assert n_bit_mismatch(img[..., :3], fx["lp_rgb_16"]) == 0
     st = t.stats()
     assert st["rays"] > 0
+    t.program_destroy(prog)
+
+
+@pytest.mark.parametrize("accel", ["brute", "bvh"])
+def test_materials_mode_random_scene_against_oracle(tracer, accel):
+    """Diffuse/emissive mode on a seeded cloud of random triangles seen from inside (rays bounce from their hit points, hit emitters,
+    leave through gaps): the all-triangles loop and the LBVH walk must both equal the CPU oracle bit for bit."""
+    from pathtracer_amd import capi
+    rng = np.random.default_rng(11)
+    nt = 400
+    base = rng.uniform(-2, 2, (nt, 1, 3)) + np.array([0, 0, 6.0])
+    tri = (base + rng.uniform(-1.6, 1.6, (nt, 3, 3))).astype(np.float32)
+    verts = np.concatenate([tri.reshape(-1, 3), np.zeros((nt * 3, 3), np.float32)], axis=1).astype(np.float32)
+    idx = np.arange(nt * 3, dtype=np.uint32).reshape(-1, 3)
+    mats = np.zeros((10, 4), np.float32)
+    mats[:, :3] = rng.uniform(0.2, 0.95, (10, 3))
+    mats[3, 3] = 7.5
+    mats[8, 3] = 2.0
+    mids = rng.integers(0, 10, nt).astype(np.int32)
+    W, H = 150, 70
+    cam = po.camera(75.0, W, H, (0.2, 0.1, 5.0), (0.0, 0.0, 7.0), (0.0, 1.0, 0.0))   # inside the cloud
+    sph, _ = po.reference_spheres_and_materials()
+    fx = {"width": W, "height": H, "variant": 1, "normal_mode": 1, "depth": 10, "camera": cam, "vertices": verts,
+          "indices": idx, "spheres": sph, "materials": mats, "shading_mode": 1, "material_ids": mids}
+    t = tracer
+    prog = setup_case(t, fx)
+    if accel == "bvh":
+        t.build_accel()
+        t.set_accel_mode(capi.ACCEL_BVH)
+    else:
+        t.set_accel_mode(capi.ACCEL_BRUTE)
+    t.reset_stats()
+    t.dispatch(1, 3, 1)
+    t.finish()
+    img = t.readback()
+    st = t.stats()
+    scene = po.Scene(verts, idx, sph, mats, mids)
+    u = po.uniforms(cam, W, H, nt, 10, 1, 1, 1)
+    ref, rays = po.render(scene, u, 1, 3, threads=8)
+    assert n_bit_mismatch(img, ref) == 0
+    assert st["rays"] == rays and rays > 2 * W * H * 3
+    if accel == "bvh":
+        assert st["bvh_node_fetches"] > 0
+    t.set_accel_mode(capi.ACCEL_AUTO)
+    t.set_shading_mode(0)
+    t.program_destroy(prog)
+
+
+def test_materials_golden_through_bvh(tracer):
+    """The llvmpipe golden of the diffuse/emissive mode, traced through the LBVH with absolute boxes."""
+    from pathtracer_amd import capi
+    fx = load_case("cornell_materials_128")
+    t = tracer
+    prog = setup_case(t, fx)
+    t.build_accel()
+    t.set_accel_mode(capi.ACCEL_BVH)
+    t.dispatch(1, 16, 1)
+    t.finish()
+    assert n_bit_mismatch(t.readback()[..., :3], fx["lp_rgb_16"]) == 0
+    assert t.stats()["bvh_node_fetches"] > 0
+    t.set_accel_mode(capi.ACCEL_AUTO)
+    t.set_shading_mode(0)
+    t.program_destroy(prog)
+
+
+def test_materials_mode_state_errors(tracer):
+    from pathtracer_amd import PtError, capi
+    fx = load_case("cornell_materials_128")
+    t = tracer
+    prog = setup_case(t, fx)
+    with pytest.raises(PtError):
+        t.upload_material_ids(fx["material_ids"][:-1])      # one id per triangle
+    bad = fx["material_ids"].copy()
+    bad[0] = -1
+    with pytest.raises(PtError):
+        t.upload_material_ids(bad)
+    t.upload_mesh(fx["vertices"], fx["indices"])             # a new mesh drops the ids
+    t.set_uniforms(fx["camera"], len(fx["indices"]), 10)
+    with pytest.raises(PtError):
+        t.dispatch(1, 1, 1)
+    t.upload_material_ids(fx["material_ids"])
+    t.set_accel_mode(capi.ACCEL_CULL)
+    with pytest.raises(PtError):
+        t.dispatch(1, 1, 1)
+    t.set_accel_mode(capi.ACCEL_AUTO)
+    t.upload_materials(fx["materials"][:2])                   # ids beyond the table
+    with pytest.raises(PtError):
+        t.dispatch(1, 1, 1)
+    t.upload_materials(fx["materials"])
+    t.dispatch(1, 1, 1)
+    t.finish()
+    t.set_shading_mode(0)
     t.program_destroy(prog)
 
 
