@@ -58,11 +58,11 @@ int RunRenderLoop(const RenderOptions& opt, Framebuffer& fb, RenderResult& resul
         result.error = err;
         return 1;
     }
-    if (opt.translate_z != 3.f || opt.custom_camera) {
-        // non-reference framing: rebuild mesh / camera with the requested values
+    std::vector<ptobj::material_t> materials;
+    if (opt.translate_z != 3.f || opt.custom_camera || opt.shade_materials) {
+        // non-reference framing or shading: rebuild mesh / camera with the requested values, keep the MTL data
         ptobj::attrib_t attrib;
         std::vector<ptobj::shape_t> shapes;
-        std::vector<ptobj::material_t> materials;
         ptobj::LoadObj(&attrib, &shapes, &materials, &err, opt.obj_path.c_str(),
                        opt.mtl_basedir.empty() ? nullptr : opt.mtl_basedir.c_str());
         scene.meshes[0] = buildMesh(attrib, shapes, 1.0f, float3(0.f, 0.f, opt.translate_z));
@@ -108,6 +108,14 @@ int RunRenderLoop(const RenderOptions& opt, Framebuffer& fb, RenderResult& resul
     std::vector<uint32_t> indices(mesh.indices.begin(), mesh.indices.end());
     PT_CHECK(pt_upload_mesh(ctx, &mesh.vertices[0].position.x, (int32_t)mesh.vertices.size(), indices.data(), result.triangles));
     PT_CHECK(pt_set_normal_mode(ctx, mesh.has_vertex_normals ? PT_NORMALS_VERTEX : PT_NORMALS_GEOMETRIC));
+    if (opt.shade_materials) {
+        const std::vector<Material> table = buildMaterialTable(materials);
+        const std::vector<int32_t> ids = resolveMaterialIds(mesh, table.size());
+        PT_CHECK(pt_upload_materials(ctx, &table[0].r, (int32_t)table.size()));
+        PT_CHECK(pt_upload_material_ids(ctx, ids.data(), (int32_t)ids.size()));
+        PT_CHECK(pt_set_shading_mode(ctx, PT_SHADE_MATERIALS));
+    }
+    if (opt.accel == 1) PT_CHECK(pt_build_accel(ctx));
     PT_CHECK(pt_enable_timing(ctx, 1));
 
     int samples = 0;

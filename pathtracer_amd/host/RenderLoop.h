@@ -26,6 +26,8 @@ struct RenderOptions {
     bool custom_camera = false;
     float eye[3] = {0, 0, 0}, target[3] = {0, 0, 1}, up[3] = {0, 1, 0}, fov = 60.f;
     float translate_z = 3.f;                         // PathTracer.cpp:1179
+    bool shade_materials = false;                    // true: PT_SHADE_MATERIALS with the table built from the MTL file
+    int accel = 0;                                   // 0 = plain loop like the shader; 1 = build the LBVH (same image)
 };
 
 struct RenderResult {

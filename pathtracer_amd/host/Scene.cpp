@@ -98,6 +98,41 @@ void buildReferenceSpheres(Scene& scene) {
     }
 }
 
+std::vector<Material> buildMaterialTable(const std::vector<ptobj::material_t>& mtl, const float3& unassigned) {
+    std::vector<Material> table;
+    table.reserve(mtl.size() + 1);
+    auto peak_of = [](const float* c) { return c[0] > c[1] ? (c[0] > c[2] ? c[0] : c[2]) : (c[1] > c[2] ? c[1] : c[2]); };
+    for (const ptobj::material_t& m : mtl) {
+        const float* emission = nullptr;
+        if (peak_of(m.emission) > 0.f) emission = m.emission;
+        else if (peak_of(m.ambient) > 1.0f) emission = m.ambient;
+        Material row;
+        if (emission) {
+            const float peak = peak_of(emission);
+            row.r = emission[0] / peak; row.g = emission[1] / peak; row.b = emission[2] / peak;
+            row.type = peak;
+        } else {
+            row.r = m.diffuse[0]; row.g = m.diffuse[1]; row.b = m.diffuse[2];
+            row.type = 0.f;
+        }
+        table.push_back(row);
+    }
+    Material grey;
+    grey.r = unassigned.x; grey.g = unassigned.y; grey.b = unassigned.z;
+    grey.type = 0.f;
+    table.push_back(grey);
+    return table;
+}
+
+std::vector<int32_t> resolveMaterialIds(const Mesh& mesh, size_t table_rows) {
+    std::vector<int32_t> ids(mesh.indices.size() / 3, (int32_t)table_rows - 1);
+    for (size_t t = 0; t < ids.size() && t < mesh.material_ids.size(); ++t) {
+        const int m = mesh.material_ids[t];
+        if (m >= 0 && (size_t)m + 1 < table_rows) ids[t] = m;
+    }
+    return ids;
+}
+
 bool buildReferenceScene(Scene& scene, const char* obj_path, const char* mtl_basedir, int width, int height, std::string* err) {
     scene.camera.position = float3(0.f, 0.f, 0.f);
     scene.camera.initialize(60.f, 0.1f, 100.f, (float)width, (float)height);

@@ -81,6 +81,16 @@ struct Scene {
 Mesh buildMesh(const ptobj::attrib_t& attrib, const std::vector<ptobj::shape_t>& shapes, float scale = 1.0f,
                const float3& translation = float3(0.0f, 0.0f, 3.f));
 
+// Table for the diffuse/emissive shading mode (PT_SHADE_MATERIALS), one row per MTL material plus a last row for
+// triangles without `usemtl`. The reference parses MTL files (tiny_obj_loader.h:956-1324) and never looks at the result,
+// so the rule is this build's: emission = Ke, or Ka when Ke is zero and a Ka component exceeds 1 (cornell_box.mtl marks
+// its light with `Ka 20 20 20` and has no Ke). An emitter is stored as (colour / peak, peak) with peak = the largest
+// component; everything else as (Kd, 0). Material::type holds the fourth value.
+std::vector<Material> buildMaterialTable(const std::vector<ptobj::material_t>& mtl, const float3& unassigned = float3(0.5f));
+// Per-triangle row numbers for that table: the mesh's material ids with -1 (and anything outside the table) mapped to
+// the last row.
+std::vector<int32_t> resolveMaterialIds(const Mesh& mesh, size_t table_rows);
+
 // PathTracer.cpp:765-768
 float nextFloat(float min, float max);
 // PathTracer.cpp:1216-1244: srand(2 ^ 17 - 1) -- an XOR, i.e. srand(18) -- then ten spheres and ten materials

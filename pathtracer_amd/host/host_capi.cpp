@@ -84,6 +84,12 @@ PTH_API void pth_obj_material(const PthObj* o, int i, char* name, int cap, float
     values19[18] = (float)m.illum;
 }
 
+// (materials + 1) rows of (r, g, b, e): the table of the diffuse/emissive shading mode built from the MTL statements.
+PTH_API void pth_obj_material_table(const PthObj* o, float* rows4) {
+    const std::vector<pthost::Material> t = pthost::buildMaterialTable(o->materials);
+    memcpy(rows4, t.data(), t.size() * sizeof(pthost::Material));
+}
+
 // Mesh as main() builds it: vertices6 = positions x {pos, normal}, indices = triangles x 3, material_ids per triangle.
 // Returns 1 when the OBJ carries a normal for every position (vertex-normal mode usable), else 0.
 PTH_API int pth_obj_build_mesh(const PthObj* o, float scale, float translate_z, float* vertices6, unsigned* indices, int* material_ids) {
@@ -124,6 +130,54 @@ PTH_API int pth_shader_stage_for_file(const char* filename) {
     return (int)s.getStage();
 }
 
+// Plain-C mirror of pthost::RenderOptions for callers that need more than pth_render offers.
+struct PthRenderOptions {
+    const char* obj_path;
+    const char* mtl_basedir;   // may be NULL
+    const char* output_tga;    // may be NULL
+    int width, height, passes, samples_per_dispatch, program_kind, device, depth;
+    int shade_materials;       // 1 = PT_SHADE_MATERIALS with the MTL-derived table
+    int accel;                 // 1 = build the LBVH
+    int custom_camera;         // 1 = use eye/target/up/fov below instead of the reference's camera
+    float eye[3], target[3], up[3], fov;
+    float translate_z;
+};
+
+static int run_loop(const pthost::RenderOptions& opt, float* rgb_sum, unsigned char* rgba8, double* stats3, char* err, int err_cap) {
+    Framebuffer fb;
+    pthost::RenderResult res;
+    const int rc = pthost::RunRenderLoop(opt, fb, res);
+    if (rc == 0) {
+        const size_t n = (size_t)opt.width * opt.height;
+        if (rgb_sum) memcpy(rgb_sum, fb.accumulationBuffer, n * 3 * sizeof(float));
+        if (rgba8) memcpy(rgba8, fb.colorBuffer, n * 4);
+        if (stats3) { stats3[0] = (double)res.rays; stats3[1] = (double)res.samples; stats3[2] = res.device_ms; }
+    }
+    copy_text(err, err_cap, res.error);
+    fb.destroy();
+    return rc;
+}
+
+PTH_API int pth_render_ex(const PthRenderOptions* o, float* rgb_sum, unsigned char* rgba8, double* stats3, char* err, int err_cap) {
+    pthost::RenderOptions opt;
+    opt.obj_path = o->obj_path;
+    opt.mtl_basedir = o->mtl_basedir ? o->mtl_basedir : "";
+    opt.output_tga = o->output_tga ? o->output_tga : "";
+    opt.width = o->width; opt.height = o->height; opt.passes = o->passes;
+    opt.samples_per_dispatch = o->samples_per_dispatch;
+    opt.program_kind = o->program_kind;
+    opt.device = o->device;
+    opt.depth = o->depth;
+    opt.shade_materials = o->shade_materials != 0;
+    opt.accel = o->accel;
+    opt.custom_camera = o->custom_camera != 0;
+    for (int k = 0; k < 3; ++k) { opt.eye[k] = o->eye[k]; opt.target[k] = o->target[k]; opt.up[k] = o->up[k]; }
+    opt.fov = o->fov;
+    opt.translate_z = o->translate_z;
+    opt.quiet = true;
+    return run_loop(opt, rgb_sum, rgba8, stats3, err, err_cap);
+}
+
 // The whole render loop. rgb_sum (may be NULL) receives Framebuffer::accumulationBuffer (w*h*3), rgba8 (may be NULL)
 // Framebuffer::colorBuffer (w*h*4). stats3 = rays, samples, device milliseconds. Returns 0 on success.
 PTH_API int pth_render(const char* obj_path, const char* mtl_basedir, int width, int height, int passes, int samples_per_dispatch,
@@ -140,16 +194,5 @@ PTH_API int pth_render(const char* obj_path, const char* mtl_basedir, int width,
     opt.device = device;
     opt.quiet = true;
     opt.output_tga = output_tga ? output_tga : "";
-    Framebuffer fb;
-    pthost::RenderResult res;
-    const int rc = pthost::RunRenderLoop(opt, fb, res);
-    if (rc == 0) {
-        const size_t n = (size_t)width * height;
-        if (rgb_sum) memcpy(rgb_sum, fb.accumulationBuffer, n * 3 * sizeof(float));
-        if (rgba8) memcpy(rgba8, fb.colorBuffer, n * 4);
-        if (stats3) { stats3[0] = (double)res.rays; stats3[1] = (double)res.samples; stats3[2] = res.device_ms; }
-    }
-    copy_text(err, err_cap, res.error);
-    fb.destroy();
-    return rc;
+    return run_loop(opt, rgb_sum, rgba8, stats3, err, err_cap);
 }

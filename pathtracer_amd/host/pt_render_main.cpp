@@ -1,6 +1,7 @@
 // Command-line front end of the render loop: the headless counterpart of the reference executable.
 //   pt_render [--obj file.obj] [--mtl-dir dir/] [--size WxH] [--passes N] [--batch N] [--kind world|mesh]
-//             [--device N] [--out image.tga] [--quiet]
+//             [--device N] [--out image.tga] [--quiet] [--shading reference|materials] [--accel loop|bvh]
+//             [--translate-z Z] [--camera ex,ey,ez,tx,ty,tz,fov]
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -23,6 +24,15 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--depth")) opt.depth = atoi(next("--depth"));
         else if (!strcmp(argv[i], "--device")) opt.device = atoi(next("--device"));
         else if (!strcmp(argv[i], "--kind")) { const char* k = next("--kind"); opt.program_kind = !strcmp(k, "mesh") ? 1 : 0; }
+        else if (!strcmp(argv[i], "--shading")) opt.shade_materials = !strcmp(next("--shading"), "materials");
+        else if (!strcmp(argv[i], "--accel")) opt.accel = !strcmp(next("--accel"), "bvh") ? 1 : 0;
+        else if (!strcmp(argv[i], "--translate-z")) opt.translate_z = (float)atof(next("--translate-z"));
+        else if (!strcmp(argv[i], "--camera")) {
+            // eye, target, vertical field of view in degrees
+            if (sscanf(next("--camera"), "%f,%f,%f,%f,%f,%f,%f", &opt.eye[0], &opt.eye[1], &opt.eye[2], &opt.target[0], &opt.target[1],
+                       &opt.target[2], &opt.fov) != 7) { fprintf(stderr, "--camera ex,ey,ez,tx,ty,tz,fov\n"); return 2; }
+            opt.custom_camera = true;
+        }
         else if (!strcmp(argv[i], "--out")) opt.output_tga = next("--out");
         else if (!strcmp(argv[i], "--quiet")) opt.quiet = true;
         else { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }

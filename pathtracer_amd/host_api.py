@@ -10,6 +10,15 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpt_host.so")
 _lib = None
 
 
+class PthRenderOptions(C.Structure):
+    """Mirror of struct PthRenderOptions (host/host_capi.cpp)."""
+    _fields_ = [("obj_path", C.c_char_p), ("mtl_basedir", C.c_char_p), ("output_tga", C.c_char_p),
+                ("width", C.c_int), ("height", C.c_int), ("passes", C.c_int), ("samples_per_dispatch", C.c_int),
+                ("program_kind", C.c_int), ("device", C.c_int), ("depth", C.c_int), ("shade_materials", C.c_int),
+                ("accel", C.c_int), ("custom_camera", C.c_int), ("eye", C.c_float * 3), ("target", C.c_float * 3),
+                ("up", C.c_float * 3), ("fov", C.c_float), ("translate_z", C.c_float)]
+
+
 def load():
     global _lib
     if _lib is None:
@@ -23,6 +32,9 @@ def load():
         L.pth_obj_copy.argtypes = [C.c_void_p] + [C.c_void_p] * 6
         L.pth_obj_shape_name.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int]
         L.pth_obj_material.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_void_p]
+        L.pth_obj_material_table.argtypes = [C.c_void_p, C.c_void_p]
+        L.pth_render_ex.restype = C.c_int
+        L.pth_render_ex.argtypes = [C.POINTER(PthRenderOptions), C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
         L.pth_obj_build_mesh.restype = C.c_int
         L.pth_obj_build_mesh.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         L.pth_camera.argtypes = [C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -72,6 +84,9 @@ class ObjFile:
                 L.pth_obj_material(h, i, name, len(name), vals[i].ctypes.data)
                 self.mat_names.append(name.value.decode())
             self.mat_values = vals
+            # (r, g, b, e) rows of the diffuse/emissive shading mode, one per material + one for "no material"
+            self.material_table = np.zeros((nm + 1, 4), np.float32)
+            L.pth_obj_material_table(h, self.material_table.ctypes.data)
             # the mesh as main() builds it
             self._mesh_cache = {}
             self._handle_counts = (nv, nt)
@@ -118,15 +133,34 @@ def shader_stage_for_file(filename):
     return STAGES[load().pth_shader_stage_for_file(filename.encode())]
 
 
-def render(obj_path, width, height, passes, samples_per_dispatch=1, program_kind=1, device=0, mtl_basedir=None, output_tga=None):
-    """Runs the C++ render loop; returns (accumulationBuffer [h,w,3] running sum, colorBuffer [h,w,4] uint8, stats)."""
+def render(obj_path, width, height, passes, samples_per_dispatch=1, program_kind=1, device=0, mtl_basedir=None, output_tga=None,
+           shading="reference", accel="loop", camera_eye_target_fov=None, translate_z=3.0, depth=10):
+    """Runs the C++ render loop; returns (accumulationBuffer [h,w,3] running sum, colorBuffer [h,w,4] uint8, stats).
+    shading "materials" = PT_SHADE_MATERIALS with the table built from the OBJ's MTL file; accel "bvh" builds the LBVH;
+    camera_eye_target_fov = (eye xyz, target xyz, fov degrees) replaces the reference's fixed camera."""
     rgb = np.zeros((height, width, 3), np.float32)
     rgba8 = np.zeros((height, width, 4), np.uint8)
     stats = np.zeros(3, np.float64)
     err = C.create_string_buffer(1024)
-    rc = load().pth_render(obj_path.encode(), mtl_basedir.encode() if mtl_basedir else None, width, height, passes,
-                           samples_per_dispatch, program_kind, device, output_tga.encode() if output_tga else None,
-                           rgb.ctypes.data, rgba8.ctypes.data, stats.ctypes.data, err, len(err))
+    o = PthRenderOptions()
+    o.obj_path = obj_path.encode()
+    o.mtl_basedir = mtl_basedir.encode() if mtl_basedir else None
+    o.output_tga = output_tga.encode() if output_tga else None
+    o.width, o.height, o.passes, o.samples_per_dispatch = width, height, passes, samples_per_dispatch
+    o.program_kind, o.device, o.depth = program_kind, device, depth
+    o.shade_materials = 1 if shading == "materials" else 0
+    o.accel = 1 if accel == "bvh" else 0
+    o.translate_z = translate_z
+    o.up[:] = (0.0, 1.0, 0.0)
+    o.target[:] = (0.0, 0.0, 1.0)
+    o.fov = 60.0
+    if camera_eye_target_fov is not None:
+        eye, target, fov = camera_eye_target_fov
+        o.custom_camera = 1
+        o.eye[:] = [float(v) for v in eye]
+        o.target[:] = [float(v) for v in target]
+        o.fov = float(fov)
+    rc = load().pth_render_ex(C.byref(o), rgb.ctypes.data, rgba8.ctypes.data, stats.ctypes.data, err, len(err))
     if rc != 0:
         raise RuntimeError(err.value.decode(errors="replace"))
     return rgb, rgba8, {"rays": int(stats[0]), "samples": int(stats[1]), "device_ms": float(stats[2])}

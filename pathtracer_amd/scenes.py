@@ -70,7 +70,9 @@ class SceneData:
         o = host_api.ObjFile(os.path.join(ASSETS, obj), ASSETS + "/")
         mesh = o.mesh_default if view["translate_z"] == 3.0 else o.mesh_untranslated
         self.vertices, self.indices = mesh["vertices"], mesh["indices"]
-        self.material_ids = mesh["material_ids"]
+        # rows for the diffuse/emissive shading mode: MTL-derived table, "no material" -> its last row
+        self.material_table = o.material_table
+        self.material_ids = np.where(mesh["material_ids"] < 0, len(o.material_table) - 1, mesh["material_ids"]).astype(np.int32)
         self.normal_mode = capi.NORMALS_VERTEX if mesh["has_vertex_normals"] else capi.NORMALS_GEOMETRIC
         self.camera = host_api.camera(view["fov"], self.width, self.height, view["eye"], view["target"], view["up"])
         self.spheres, self.materials = host_api.reference_spheres()
@@ -85,14 +87,20 @@ class SceneData:
         base = o.mesh_untranslated
         unit = 30.0
         self.vertices, self.indices = instanced_mesh(base["vertices"], base["indices"], unit=unit)
-        self.material_ids = np.zeros(len(self.indices), np.int32)
+        # diffuse/emissive mode: one colour per instance, every 16th instance a lamp
+        tris_per = len(base["indices"])
+        inst = np.arange(len(self.indices)) // tris_per
+        self.material_ids = (inst % 8).astype(np.int32)
+        self.material_table = np.array([[0.8, 0.8, 0.8, 0], [0.8, 0.3, 0.3, 0], [0.3, 0.8, 0.3, 0], [0.3, 0.3, 0.8, 0],
+                                        [0.8, 0.8, 0.3, 0], [0.3, 0.8, 0.8, 0], [0.8, 0.3, 0.8, 0], [1.0, 0.9, 0.7, 6.0]], np.float32)
         self.normal_mode = capi.NORMALS_GEOMETRIC
         self.camera = host_api.camera(60.0, self.width, self.height, (0.0, 0.0, -44.0 * unit), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0))
         self.spheres, self.materials = host_api.reference_spheres()
         self.num_triangles = len(self.indices)
 
-    def upload(self, tracer, depth=10, accel=True):
-        """Scene upload + program + uniforms on a Tracer; the target is the caller's business."""
+    def upload(self, tracer, depth=10, accel=True, shading="reference"):
+        """Scene upload + program + uniforms on a Tracer; the target is the caller's business. shading "materials"
+        selects the diffuse/emissive mode with the scene's material table (mesh programs only)."""
         prog = tracer.program_create(self.program)
         tracer.use_program(prog)
         tracer.upload_spheres(self.spheres)
@@ -100,6 +108,12 @@ class SceneData:
         tracer.upload_mesh(self.vertices, self.indices)
         tracer.set_normal_mode(self.normal_mode)
         tracer.set_uniforms(self.camera, self.num_triangles, depth)
+        if shading == "materials":
+            tracer.upload_materials(self.material_table)
+            tracer.upload_material_ids(self.material_ids)
+            tracer.set_shading_mode(capi.SHADE_MATERIALS)
+        else:
+            tracer.set_shading_mode(capi.SHADE_REFERENCE)
         if accel:
             tracer.build_accel()   # used by dispatches when the mesh is large enough (PT_ACCEL_AUTO)
         return prog

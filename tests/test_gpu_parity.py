@@ -296,3 +296,18 @@ def test_cpp_host_render_loop(tmp_path):
     # batching frames into one dispatch gives the same picture
     rgb_sum2, _, _ = host_api.render(os.path.join(ASSETS, "monkeyhead2.obj"), 128, 128, 16, samples_per_dispatch=16, program_kind=1)
     assert n_bit_mismatch(rgb_sum2, rgb_sum) == 0
+
+
+@pytest.mark.parametrize("accel", ["loop", "bvh"])
+def test_cpp_host_materials_mode(accel):
+    """C++ host end to end in the diffuse/emissive mode: OBJ + MTL -> material table and per-triangle ids -> 16 frames;
+    the Framebuffer must hold the llvmpipe golden of the Cornell box."""
+    import os
+    from pathtracer_amd import host_api
+    from pathtracer_amd.scenes import ASSETS
+    fx = load_case("cornell_materials_128")
+    rgb_sum, _, st = host_api.render(os.path.join(ASSETS, "cornell_box.obj"), 128, 128, 16, samples_per_dispatch=4, program_kind=1,
+                                     mtl_basedir=ASSETS + "/", shading="materials", accel=accel,
+                                     camera_eye_target_fov=((278, 273, -800), (278, 273, 0), 39.3), translate_z=0.0)
+    assert n_bit_mismatch(rgb_sum, fx["lp_rgb_16"] * np.float32(16.0)) == 0
+    assert st["samples"] == 128 * 128 * 16

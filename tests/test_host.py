@@ -47,6 +47,25 @@ def test_mtl_lookup_follows_basedir_rule(tmp_path):
     assert tuple(light[0:3]) == (20.0, 20.0, 20.0)  # Ka 20 20 20: the "light" is ambient, there is no Ke
 
 
+def test_material_table_rule(tmp_path):
+    """MTL -> (r, g, b, e) rows of the diffuse/emissive mode: the C++ host against the rule as the oracle front end states
+    it, the table the golden case was rendered with, and a hand-written MTL with Ke."""
+    o = host.ObjFile(f"{A}/cornell_box.obj", A + "/")
+    assert o.material_table.shape == (6, 4)
+    assert n_bit_mismatch(o.material_table, po.material_table_from_mtl(o.mat_values)) == 0
+    fx = np.load(f"{GOLDEN}/case_cornell_materials_128.npz")
+    assert n_bit_mismatch(o.material_table, fx["materials"][:6]) == 0
+    assert tuple(o.material_table[4]) == (1.0, 1.0, 1.0, 20.0)          # light: Ka 20 20 20 -> white x 20
+    assert tuple(o.material_table[5]) == (0.5, 0.5, 0.5, 0.0)            # row for triangles without usemtl
+    ids = np.where(o.mat_ids < 0, 5, o.mat_ids)
+    assert np.array_equal(ids, fx["material_ids"])
+    (tmp_path / "m.mtl").write_text("newmtl lamp\nKd 0.1 0.2 0.3\nKe 2 4 1\nnewmtl wall\nKa 0.9 0.9 0.9\nKd 0.25 0.5 0.75\n")
+    (tmp_path / "m.obj").write_text("mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nusemtl lamp\nf 1 2 3\nusemtl wall\nf 3 2 1\n")
+    o = host.ObjFile(str(tmp_path / "m.obj"), str(tmp_path) + "/")
+    assert np.allclose(o.material_table, [[0.5, 1.0, 0.25, 4.0], [0.25, 0.5, 0.75, 0.0], [0.5, 0.5, 0.5, 0.0]])
+    assert list(o.mat_ids) == [0, 1]
+
+
 def test_float_text_grammar():
     cases = {"1": 1.0, "-0": -0.0, "+3.1417e+2": 314.17, "-0.0E-3": -0.0, "1.0324": 1.0324, "11e2": 1100.0,
              "552.8": 552.8, "0.437500": 0.4375, "1.": 1.0, "1e": 0.0, ".5": 0.0, "abc": 0.0, "": 0.0, "2.5x": 2.5,

@@ -18,12 +18,13 @@ def main():
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--lib", default=None)
     ap.add_argument("--accel", default="auto", choices=["auto", "brute", "bvh", "cull"])
+    ap.add_argument("--shading", default="reference", choices=["reference", "materials"])
     args = ap.parse_args()
     from pathtracer_amd import Tracer
     from pathtracer_amd.scenes import SceneData
     scene = SceneData(args.workload, args.width, args.height)
     t = Tracer(0, args.lib)
-    scene.upload(t)
+    scene.upload(t, shading=args.shading)
     t.target_create(scene.width, scene.height)
     if args.accel == "bvh":
         import time
@@ -48,7 +49,7 @@ def main():
     st = t.stats()
     ms = st["total_dispatch_ms"] / st["dispatches"]
     print(json.dumps({"workload": args.workload, "size": [scene.width, scene.height], "spp": args.spp, "triangles": scene.num_triangles,
-                      "accel": args.accel, "bvh_build_s": round(build_s, 4), "kernel_ms": ms, "per_rep_ms": per_rep, "Grays_per_s": st["rays"] / st["dispatches"] / ms * 1e-6,
+                      "accel": args.accel, "shading": args.shading, "bvh_build_s": round(build_s, 4), "kernel_ms": ms, "per_rep_ms": per_rep, "Grays_per_s": st["rays"] / st["dispatches"] / ms * 1e-6,
                       "rays_per_sample": st["rays"] / st["samples"], "lane_utilisation": st["rays"] / st["lane_slots"],
                       "triangle_records_per_wave_ray": st["bvh_triangle_fetches"] * 64 / st["lane_slots"],
                       "node_records_per_wave_ray": st["bvh_node_fetches"] * 64 / st["lane_slots"]}))
