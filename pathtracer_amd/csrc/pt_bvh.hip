@@ -19,12 +19,14 @@ __device__ __forceinline__ float ord2f(uint32_t o) {
     return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
 }
 
-__device__ __forceinline__ uint32_t spread10(uint32_t v) {  // 10 bits -> every third bit
-    v = (v * 0x00010001u) & 0xFF0000FFu;
-    v = (v * 0x00000101u) & 0x0F00F00Fu;
-    v = (v * 0x00000011u) & 0xC30C30C3u;
-    v = (v * 0x00000005u) & 0x49249249u;
-    return v;
+__device__ __forceinline__ unsigned long long spread21(uint32_t v) {  // 21 bits -> every third bit of 63
+    unsigned long long x = v & 0x1fffffu;
+    x = (x | x << 32) & 0x001f00000000ffffull;
+    x = (x | x << 16) & 0x001f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
 }
 
 __global__ __launch_bounds__(256) void bvh_init_scene_box(uint32_t* scene_box) {
@@ -53,9 +55,10 @@ __global__ __launch_bounds__(256) void bvh_tri_boxes(const float* __restrict__ v
     }
 }
 
-// key = 30-bit Morton code of the centroid (high word) | triangle index (low word): unique, so the hierarchy is well defined
+// key = 63-bit Morton code of the centroid (21 bits per axis: fine enough that the triangles of one small object in a
+// large scene still get distinct cells); value = triangle index. Equal keys are told apart by their sorted position.
 __global__ __launch_bounds__(256) void bvh_morton_keys(const float* __restrict__ tri_box, const uint32_t* __restrict__ scene_box, int n,
-                                                       unsigned long long* __restrict__ keys) {
+                                                       unsigned long long* __restrict__ keys, uint32_t* __restrict__ order) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t q[3];
@@ -64,16 +67,18 @@ __global__ __launch_bounds__(256) void bvh_morton_keys(const float* __restrict__
         const float ctr = 0.5f * tri_box[6 * (size_t)i + k] + 0.5f * tri_box[6 * (size_t)i + 3 + k];
         const float ext = hi - lo;
         float u = ext > 0.f ? (ctr - lo) / ext : 0.f;
-        u = fminf(fmaxf(u * 1024.f, 0.f), 1023.f);
+        u = fminf(fmaxf(u * 2097152.f, 0.f), 2097151.f);
         q[k] = (uint32_t)u;
     }
-    const uint32_t code = (spread10(q[0]) << 2) | (spread10(q[1]) << 1) | spread10(q[2]);
-    keys[i] = ((unsigned long long)code << 32) | (uint32_t)i;
+    keys[i] = (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
+    order[i] = (uint32_t)i;
 }
 
 __device__ __forceinline__ int key_delta(const unsigned long long* __restrict__ keys, int n, int i, int j) {
     if (j < 0 || j >= n) return -1;
-    return __builtin_clzll(keys[i] ^ keys[j]);  // keys are distinct
+    const unsigned long long x = keys[i] ^ keys[j];
+    // equal codes: fall back to the sorted positions, which are distinct (Karras 2012, section 4)
+    return x ? __builtin_clzll(x) : 64 + __builtin_clz((uint32_t)i ^ (uint32_t)j);
 }
 
 // Karras 2012: internal node i of n-1. child refs: >= 0 internal node index; < 0 leaf at sorted position ~ref.
@@ -105,7 +110,7 @@ __global__ __launch_bounds__(256) void bvh_hierarchy(const unsigned long long* _
 
 // One bottom-up sweep: computes the box of every node whose children were finished by an EARLIER launch (done[c] in
 // [1, pass)). Kernel boundaries provide the visibility between sweeps; nothing is handed over inside a launch.
-__global__ __launch_bounds__(256) void bvh_refit_pass(const unsigned long long* __restrict__ keys, const int* __restrict__ child,
+__global__ __launch_bounds__(256) void bvh_refit_pass(const uint32_t* __restrict__ order, const int* __restrict__ child,
                                                       const float* __restrict__ tri_box, int n, int pass, float* __restrict__ node_box,
                                                       int* __restrict__ done, int* __restrict__ remaining) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -115,7 +120,7 @@ __global__ __launch_bounds__(256) void bvh_refit_pass(const unsigned long long* 
         const int ref = child[2 * i + c];
         const float* box;
         if (ref < 0) {
-            box = tri_box + 6 * (size_t)(uint32_t)(keys[~ref] & 0xffffffffull);
+            box = tri_box + 6 * (size_t)order[~ref];
         } else {
             const int dn = done[ref];
             if (dn == 0 || dn >= pass) return;
@@ -143,10 +148,10 @@ __device__ __forceinline__ uint32_t traversal_ref(int ref, const int* __restrict
     return (uint32_t)ref;
 }
 
-// Traversal record of internal node i: both children's boxes, relative to the ray origin (all rays share it) and
-// padded so that a ray the exact fp32 triangle test accepts can never fail the box test through rounding:
-// the slab arithmetic errs by ~1e-7 relative to the distance from the origin; the pad is 1e-5 of it.
-__global__ __launch_bounds__(256) void bvh_emit_nodes(const unsigned long long* __restrict__ keys, const int* __restrict__ child,
+// Traversal record of internal node i: both children's boxes as centre + half extents, relative to the ray origin (all
+// rays share it) and padded so that a ray the exact fp32 triangle test accepts can never fail the box test through
+// rounding: the slab arithmetic errs by ~1e-7 relative to the distance from the origin; the pad is 1e-5 of it.
+__global__ __launch_bounds__(256) void bvh_emit_nodes(const uint32_t* __restrict__ order, const int* __restrict__ child,
                                                       const int* __restrict__ range, const float* __restrict__ tri_box,
                                                       const float* __restrict__ node_box, int n, float rox, float roy, float roz,
                                                       float extra_pad, float* __restrict__ nodes) {
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(256) void bvh_emit_nodes(const unsigned long long* 
     float* out = nodes + (size_t)i * PT_BVH_NODE_FLOATS;
     for (int c = 0; c < 2; ++c) {
         const int ref = child[2 * i + c];
-        const float* box = ref < 0 ? tri_box + 6 * (size_t)(uint32_t)(keys[~ref] & 0xffffffffull) : node_box + 6 * (size_t)ref;
+        const float* box = ref < 0 ? tri_box + 6 * (size_t)order[~ref] : node_box + 6 * (size_t)ref;
         float rel[6], far = 0.f;
         for (int k = 0; k < 3; ++k) {
             rel[k] = box[k] - ro[k];
@@ -165,8 +170,10 @@ __global__ __launch_bounds__(256) void bvh_emit_nodes(const unsigned long long* 
         }
         const float pad = 1.0e-5f * far + extra_pad + 1.0e-30f;
         for (int k = 0; k < 3; ++k) {
-            out[6 * c + k] = rel[k] - pad;
-            out[6 * c + 3 + k] = rel[3 + k] + pad;
+            const float lo = rel[k] - pad, hi = rel[3 + k] + pad;
+            out[6 * c + k] = 0.5f * lo + 0.5f * hi;
+            // the centre is rounded (half an ulp of `far` at most): the half extent takes that up again
+            out[6 * c + 3 + k] = (0.5f * hi - 0.5f * lo) + 1.0e-6f * far;
         }
         out[12 + c] = __uint_as_float(traversal_ref(ref, range));
     }
@@ -175,13 +182,17 @@ __global__ __launch_bounds__(256) void bvh_emit_nodes(const unsigned long long* 
 }
 
 // Triangle records and ids in sorted (leaf) order; the tail is padded with all-zero records like the unsorted array.
-__global__ __launch_bounds__(256) void bvh_gather_records(const unsigned long long* __restrict__ keys, const float4* __restrict__ tris, int n,
+// The id also goes into the record's last (unused) word, so that a leaf needs no second fetch.
+__global__ __launch_bounds__(256) void bvh_gather_records(const uint32_t* __restrict__ order, const float4* __restrict__ tris, int n,
                                                           float4* __restrict__ sorted_tris, int* __restrict__ sorted_ids) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n + PT_TRI_PAD) return;
     if (k < n) {
-        const uint32_t id = (uint32_t)(keys[k] & 0xffffffffull);
-        for (int q = 0; q < 4; ++q) sorted_tris[4 * (size_t)k + q] = tris[4 * (size_t)id + q];
+        const uint32_t id = order[k];
+        for (int q = 0; q < 3; ++q) sorted_tris[4 * (size_t)k + q] = tris[4 * (size_t)id + q];
+        float4 last = tris[4 * (size_t)id + 3];
+        last.w = __uint_as_float(id);
+        sorted_tris[4 * (size_t)k + 3] = last;
         sorted_ids[k] = (int)id;
     } else {
         for (int q = 0; q < 4; ++q) sorted_tris[4 * (size_t)k + q] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -195,7 +206,8 @@ inline dim3 grid_for(int n) { return dim3((unsigned)((n + 255) / 256)); }
 
 size_t pt_bvh_sort_temp_bytes(int32_t n) {
     size_t bytes = 0;
-    (void)hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, n, 0, 64, nullptr);
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                                             (const uint32_t*)nullptr, (uint32_t*)nullptr, n, 0, 63, nullptr);
     return bytes;
 }
 
@@ -205,9 +217,9 @@ hipError_t pt_bvh_build_topology(const PtBvhBuild& b, hipStream_t stream, int32_
     if (n < 2) return hipSuccess;
     hipLaunchKernelGGL(bvh_init_scene_box, dim3(1), dim3(64), 0, stream, b.scene_box);
     hipLaunchKernelGGL(bvh_tri_boxes, grid_for(n), dim3(256), 0, stream, b.vertices, b.indices, n, b.tri_box, b.scene_box);
-    hipLaunchKernelGGL(bvh_morton_keys, grid_for(n), dim3(256), 0, stream, b.tri_box, b.scene_box, n, b.keys_tmp);
+    hipLaunchKernelGGL(bvh_morton_keys, grid_for(n), dim3(256), 0, stream, b.tri_box, b.scene_box, n, b.keys_tmp, b.order_tmp);
     size_t bytes = b.sort_tmp_bytes;
-    hipError_t e = hipcub::DeviceRadixSort::SortKeys(b.sort_tmp, bytes, b.keys_tmp, b.keys, n, 0, 64, stream);
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(b.sort_tmp, bytes, b.keys_tmp, b.keys, b.order_tmp, b.order, n, 0, 63, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(bvh_hierarchy, grid_for(n - 1), dim3(256), 0, stream, b.keys, n, b.child, b.range);
     e = hipMemsetAsync(b.done, 0, (size_t)(n - 1) * sizeof(int), stream);
@@ -215,12 +227,12 @@ hipError_t pt_bvh_build_topology(const PtBvhBuild& b, hipStream_t stream, int32_
     int remaining = n - 1;
     e = hipMemcpyAsync(b.remaining, &remaining, sizeof(int), hipMemcpyHostToDevice, stream);
     if (e != hipSuccess) return e;
-    // The tree height is at most 64 + log2(n) sweeps-worth (64-bit distinct keys); sweeps run in groups of 8 between checks.
+    // The tree height is at most 63 + 32 levels (63-bit codes, then 32-bit positions); sweeps run in groups of 8 between checks.
     int pass = 1;
     while (remaining > 0) {
         if (pass > 4096) return hipErrorUnknown;  // cannot happen for a well-formed hierarchy; never spin forever
         for (int g = 0; g < 8; ++g, ++pass)
-            hipLaunchKernelGGL(bvh_refit_pass, grid_for(n - 1), dim3(256), 0, stream, b.keys, b.child, b.tri_box, n, pass + 1, b.node_box,
+            hipLaunchKernelGGL(bvh_refit_pass, grid_for(n - 1), dim3(256), 0, stream, b.order, b.child, b.tri_box, n, pass + 1, b.node_box,
                                b.done, b.remaining);
         e = hipMemcpyAsync(&remaining, b.remaining, sizeof(int), hipMemcpyDeviceToHost, stream);
         if (e != hipSuccess) return e;
@@ -235,16 +247,16 @@ hipError_t pt_bvh_emit(const PtBvhBuild& b, const float ro[3], const float* tris
     const int n = b.num_triangles;
     if (n < 1) return hipSuccess;
     if (n >= 2) {
-        hipLaunchKernelGGL(bvh_emit_nodes, grid_for(n - 1), dim3(256), 0, stream, b.keys, b.child, b.range, b.tri_box, b.node_box, n, ro[0],
+        hipLaunchKernelGGL(bvh_emit_nodes, grid_for(n - 1), dim3(256), 0, stream, b.order, b.child, b.range, b.tri_box, b.node_box, n, ro[0],
                            ro[1], ro[2], 0.0f, b.nodes);
         // Absolute boxes for rays that start anywhere in the scene: the slab arithmetic then errs relative to the
         // larger of box and origin coordinates, so the pad also carries a term of the scene's size.
-        hipLaunchKernelGGL(bvh_emit_nodes, grid_for(n - 1), dim3(256), 0, stream, b.keys, b.child, b.range, b.tri_box, b.node_box, n, 0.0f,
+        hipLaunchKernelGGL(bvh_emit_nodes, grid_for(n - 1), dim3(256), 0, stream, b.order, b.child, b.range, b.tri_box, b.node_box, n, 0.0f,
                            0.0f, 0.0f, 4.0e-6f * b.scene_scale, b.nodes_abs);
     }
-    hipLaunchKernelGGL(bvh_gather_records, grid_for(n + PT_TRI_PAD), dim3(256), 0, stream, b.keys, reinterpret_cast<const float4*>(tris_abs), n,
+    hipLaunchKernelGGL(bvh_gather_records, grid_for(n + PT_TRI_PAD), dim3(256), 0, stream, b.order, reinterpret_cast<const float4*>(tris_abs), n,
                        reinterpret_cast<float4*>(b.sorted_tris_abs), b.sorted_ids);
-    hipLaunchKernelGGL(bvh_gather_records, grid_for(n + PT_TRI_PAD), dim3(256), 0, stream, b.keys, reinterpret_cast<const float4*>(tris), n,
+    hipLaunchKernelGGL(bvh_gather_records, grid_for(n + PT_TRI_PAD), dim3(256), 0, stream, b.order, reinterpret_cast<const float4*>(tris), n,
                        reinterpret_cast<float4*>(b.sorted_tris), b.sorted_ids);
     return hipGetLastError();
 }

@@ -89,10 +89,16 @@ struct PtContext {
     float* d_t = nullptr;
     // tile scheduling: per-tile cost of the last dispatch and the order derived from it
     uint32_t* d_tile_cost = nullptr;
-    uint32_t* d_tile_order = nullptr;
+    PtWorkItem* d_items = nullptr;        // tiles + max_split entries
+    uint32_t* d_sched_counts = nullptr;   // 2
+    uint32_t* d_split_tiles = nullptr;    // max_split entries
+    float* d_sample_scratch = nullptr;    // grows with the largest num_samples dispatched
+    size_t sample_scratch_bytes = 0;
+    int32_t wave_slots = 0;               // waves the device holds at once (CUs x 4 SIMDs x 8)
+    float split_factor = -1.f;            // < 0: chosen per kernel family, see pt_dispatch
     int32_t sched_win[4] = {-1, -1, -1, -1};  // window the costs were measured for
     bool sched_have_cost = false;
-    bool sched_enabled = true;
+    int sched_mode = 2;             // 0 raster order, 1 cost-ordered tiles, 2 cost-ordered items with heavy tiles split by samples
 
     // uniforms
     PtUniforms uniforms{};
@@ -110,6 +116,8 @@ struct PtContext {
 };
 
 namespace {
+
+constexpr int PT_MAX_SPLIT_FACTOR = 8;  // arrays of the scheduler are sized for this many split tiles per wave slot
 
 PtStatus bind(PtContext* ctx) {
     PT_REQUIRE(ctx != nullptr, PT_ERR_INVALID_ARGUMENT, "null context");
@@ -145,17 +153,24 @@ void free_target(PtContext* ctx) {
     if (ctx->d_ids) (void)hipFree(ctx->d_ids);
     if (ctx->d_t) (void)hipFree(ctx->d_t);
     if (ctx->d_tile_cost) (void)hipFree(ctx->d_tile_cost);
-    if (ctx->d_tile_order) (void)hipFree(ctx->d_tile_order);
+    if (ctx->d_items) (void)hipFree(ctx->d_items);
+    if (ctx->d_sched_counts) (void)hipFree(ctx->d_sched_counts);
+    if (ctx->d_split_tiles) (void)hipFree(ctx->d_split_tiles);
+    if (ctx->d_sample_scratch) (void)hipFree(ctx->d_sample_scratch);
+    ctx->d_items = nullptr;
+    ctx->d_sched_counts = ctx->d_split_tiles = nullptr;
+    ctx->d_sample_scratch = nullptr;
+    ctx->sample_scratch_bytes = 0;
     ctx->d_ids = nullptr;
     ctx->d_t = nullptr;
-    ctx->d_tile_cost = ctx->d_tile_order = nullptr;
+    ctx->d_tile_cost = nullptr;
     ctx->sched_have_cost = false;
     ctx->width = ctx->height = 0;
 }
 
 void free_bvh(PtContext* ctx) {
     PtBvhBuild& b = ctx->bvh;
-    void* ptrs[] = {b.tri_box, b.scene_box, b.keys_tmp, b.keys, b.sort_tmp, b.child, b.range, b.node_box, b.done, b.remaining,
+    void* ptrs[] = {b.tri_box, b.scene_box, b.keys_tmp, b.keys, b.order_tmp, b.order, b.sort_tmp, b.child, b.range, b.node_box, b.done, b.remaining,
                     b.nodes, b.sorted_tris, b.sorted_ids, b.nodes_abs, b.sorted_tris_abs};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
@@ -316,9 +331,13 @@ PtStatus pt_create(int32_t device, PtContext** out_ctx) {
         return fail(PT_ERR_HIP, "context set-up failed: %s", hipGetErrorString(err));
     }
     ctx->stream = ctx->own_stream;
-    // PT_TILE_SCHEDULE=0 renders tiles in raster order (for measuring what the cost-ordered schedule is worth)
+    // PT_TILE_SCHEDULE=0 renders tiles in raster order, =tile orders whole tiles by cost, default: cost-ordered work
+    // list in which expensive tiles are split by samples (for measuring what the schedules are worth)
     const char* sched = getenv("PT_TILE_SCHEDULE");
-    ctx->sched_enabled = !(sched && sched[0] == '0');
+    if (sched && sched[0] == '0') ctx->sched_mode = 0;
+    else if (sched && sched[0] == 't') ctx->sched_mode = 1;
+    ctx->wave_slots = prop.multiProcessorCount * 4 * 8;
+    if (const char* f = getenv("PT_SPLIT_FACTOR")) ctx->split_factor = (float)atof(f);  // for experiments
     *out_ctx = ctx;
     return PT_OK;
 }
@@ -496,6 +515,8 @@ PtStatus pt_build_accel(PtContext* ctx) {
     alloc(&b.scene_box, 6 * sizeof(uint32_t));
     alloc(&b.keys_tmp, nn * sizeof(unsigned long long));
     alloc(&b.keys, nn * sizeof(unsigned long long));
+    alloc(&b.order_tmp, nn * sizeof(uint32_t));
+    alloc(&b.order, nn * sizeof(uint32_t));
     alloc(&b.sort_tmp, b.sort_tmp_bytes);
     alloc(&b.child, ni * 2 * sizeof(int));
     alloc(&b.range, ni * 2 * sizeof(int));
@@ -541,7 +562,9 @@ static PtStatus target_common(PtContext* ctx, int32_t width, int32_t height) {
     PT_HIP_TRY(hipMalloc(&ctx->d_t, n * sizeof(float)));
     const size_t tiles = (size_t)PT_TILES_ACROSS(width) * PT_TILES_ACROSS(height);
     PT_HIP_TRY(hipMalloc(&ctx->d_tile_cost, tiles * sizeof(uint32_t)));
-    PT_HIP_TRY(hipMalloc(&ctx->d_tile_order, tiles * sizeof(uint32_t)));
+    PT_HIP_TRY(hipMalloc(&ctx->d_items, (tiles + (size_t)PT_MAX_SPLIT_FACTOR * ctx->wave_slots) * sizeof(PtWorkItem)));
+    PT_HIP_TRY(hipMalloc(&ctx->d_sched_counts, 2 * sizeof(uint32_t)));
+    PT_HIP_TRY(hipMalloc(&ctx->d_split_tiles, (size_t)PT_MAX_SPLIT_FACTOR * ctx->wave_slots * sizeof(uint32_t)));
     ctx->sched_have_cost = false;
     return PT_OK;
 }
@@ -641,15 +664,42 @@ PtStatus pt_dispatch(PtContext* ctx, int32_t first_sample, int32_t num_samples, 
     // Tile order: the costs measured by the previous dispatch of this same window put the expensive tiles first.
     // It is only a scheduling hint (any order renders the same image), so stale costs after a camera or scene change
     // are harmless.
-    if (ctx->sched_enabled) {
+    if (ctx->sched_mode != 0) {
         const int tiles = PT_TILES_ACROSS(ctx->win[2]) * PT_TILES_ACROSS(ctx->win[3]);
         const bool same_window = memcmp(ctx->sched_win, ctx->win, sizeof ctx->win) == 0;
         if (ctx->sched_have_cost && same_window) {
-            PT_HIP_TRY(pt_launch_schedule_tiles(ctx->d_tile_cost, ctx->d_tile_order, tiles, ctx->stream));
-            p.tile_order = ctx->d_tile_order;
+            // Split tiles park their samples in scratch memory: max_split slots of num_samples x tile pixels x 16 bytes,
+            // grown on demand and capped at 8 GiB (fewer splits beyond that).
+            // How eagerly tiles are split (a tile is split when its cost exceeds total / (factor x wave slots)): the
+            // all-triangles loop is throughput-bound and every extra block adds a drain phase in which lanes idle, so only
+            // tiles longer than the whole balanced kernel are split (measured on the 36-triangle scene: factor 0: 30.9 ms,
+            // 1: 31.0, 2: 31.5, 4: 31.9); the hierarchy walk is latency-bound and gains from every additional wave
+            // (968 triangles: 8.7 ms unsplit, 3.1 at factor 1, 2.6 at factor 4).
+            float factor = (p.bvh_nodes || p.bvh_nodes_abs) ? 4.0f : 1.0f;
+            if (ctx->split_factor >= 0.f) factor = ctx->split_factor < (float)PT_MAX_SPLIT_FACTOR ? ctx->split_factor : (float)PT_MAX_SPLIT_FACTOR;
+            int max_split = (ctx->sched_mode == 2 && num_samples > 1) ? (int)(factor * (float)ctx->wave_slots) : 0;
+            const size_t slot_bytes = (size_t)num_samples * PT_TILE_THREADS * 16;
+            const size_t cap = (size_t)8 << 30;
+            if (max_split > 0 && slot_bytes * (size_t)max_split > cap) max_split = (int)(cap / slot_bytes);
+            if (max_split > 0 && slot_bytes * (size_t)max_split > ctx->sample_scratch_bytes) {
+                PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
+                if (ctx->d_sample_scratch) (void)hipFree(ctx->d_sample_scratch);
+                ctx->d_sample_scratch = nullptr;
+                ctx->sample_scratch_bytes = 0;
+                PT_HIP_TRY(hipMalloc(&ctx->d_sample_scratch, slot_bytes * (size_t)max_split));
+                ctx->sample_scratch_bytes = slot_bytes * (size_t)max_split;
+            }
+            PT_HIP_TRY(pt_launch_schedule_items(ctx->d_tile_cost, ctx->d_items, ctx->d_sched_counts, ctx->d_split_tiles, tiles, num_samples,
+                                                max_split, ctx->stream));
+            p.items = ctx->d_items;
+            p.sched_counts = ctx->d_sched_counts;
+            p.split_tiles = ctx->d_split_tiles;
+            p.sample_scratch = ctx->d_sample_scratch;
+            p.max_items = tiles + max_split;
+            p.max_split_tiles = max_split;
         } else {
             PT_HIP_TRY(hipMemsetAsync(ctx->d_tile_cost, 0, (size_t)tiles * sizeof(uint32_t), ctx->stream));
-            p.tile_order = nullptr;
+            p.items = nullptr;
         }
         p.tile_cost = ctx->d_tile_cost;
         memcpy(ctx->sched_win, ctx->win, sizeof ctx->win);

@@ -25,7 +25,8 @@ struct PtTriRecordLayout {
 };
 
 // LBVH: traversal record of one internal node, 16 floats = 64 bytes (one scalar fetch):
-//   [0..5] left child box min/max, [6..11] right child box min/max -- relative to the ray origin, padded
+//   [0..2] left child box centre, [3..5] its half extents, [6..8] right centre, [9..11] right half extents -- relative
+//   to the ray origin (or absolute, for rays with their own origins), padded
 //   [12] left ref, [13] right ref (uint bits): 0x80000000 | first << 3 | count-1 = leaf of `count` triangles starting
 //   at sorted position `first`; otherwise the index of an internal node.
 #define PT_BVH_NODE_FLOATS 16
@@ -43,7 +44,9 @@ struct PtBvhBuild {
     float* tri_box;               // n x 6, absolute, original triangle order
     uint32_t* scene_box;          // 6 order-preserving uints: centroid bounds
     unsigned long long* keys_tmp; // n
-    unsigned long long* keys;     // n, sorted: Morton code << 32 | triangle id
+    unsigned long long* keys;     // n, sorted 63-bit Morton codes of the centroids (duplicates allowed)
+    uint32_t* order_tmp;          // n
+    uint32_t* order;              // n: triangle id at each sorted position
     void* sort_tmp;
     size_t sort_tmp_bytes;
     int* child;                   // (n-1) x 2
@@ -81,6 +84,16 @@ hipError_t pt_bvh_emit(const PtBvhBuild& b, const float ro[3], const float* tris
 #define PT_TILE_THREADS (64 * PT_TILE_WAVES)
 #define PT_TILES_ACROSS(n) (((n) + PT_TILE_DIM - 1) / PT_TILE_DIM)
 
+// One block's work: `sample_count` consecutive samples (from the dispatch's sample_begin-th on) of one tile. A tile
+// with scratch_slot < 0 has a single item that folds its samples into the image itself; the items of a split tile write
+// their samples to the scratch slot and a second kernel folds them in sample order.
+struct PtWorkItem {
+    uint32_t tile;
+    uint32_t sample_begin;
+    uint32_t sample_count;
+    int32_t scratch_slot;
+};
+
 struct PtKernelParams {
     float ro[3], llc[3], hor[3], ver[3];
     int32_t width, height;              // full frame: textureSize(u_Texture, 0)
@@ -106,7 +119,11 @@ struct PtKernelParams {
     const float* src;                   // RGBA32F image read (previous result)
     float* dst;                         // RGBA32F image written
     unsigned long long* counters;       // [0] rays, [1] lane slots spent (wave loop trips x 64)
-    const uint32_t* tile_order;         // permutation of the window's tiles (block -> tile), or null = identity
+    const PtWorkItem* items;            // work list (block -> item), or null = block b renders tile b with all samples
+    const uint32_t* sched_counts;       // [0] number of items, [1] number of split tiles (device scalars written by the scheduler)
+    const uint32_t* split_tiles;        // scratch slot -> tile
+    float* sample_scratch;              // slots x num_samples x 64 lanes x (r, g, b, -): samples of split tiles, folded afterwards
+    int32_t max_items, max_split_tiles; // launch sizes (upper bounds of the two counts)
     uint32_t* tile_cost;                // per tile: loop trips spent on it in this dispatch (scheduling hint), or null
     int32_t* out_ids;                   // primary pass only
     float* out_t;                       // primary pass only
@@ -119,6 +136,9 @@ hipError_t pt_launch_prepare_triangles(const float* vertices, const uint32_t* in
 hipError_t pt_launch_fill_rgba(float* img, size_t num_pixels, float r, float g, float b, float a, hipStream_t stream);
 hipError_t pt_launch_render(const PtKernelParams& p, int program_kind, hipStream_t stream);
 hipError_t pt_launch_present(const float* img, size_t num_pixels, uint32_t* out_rgba8, hipStream_t stream);
-// tile_order <- tiles sorted by descending tile_cost (bucketed); tile_cost <- 0
-hipError_t pt_launch_schedule_tiles(uint32_t* tile_cost, uint32_t* tile_order, int num_tiles, hipStream_t stream);
+// Work list for the next dispatch from the per-tile costs of the previous one: tiles whose cost exceeds
+// total / max_split_tiles are split into several items (at most num_samples), items ordered most expensive first.
+// Always: item count <= num_tiles + max_split_tiles and split tiles <= max_split_tiles. tile_cost <- 0.
+hipError_t pt_launch_schedule_items(uint32_t* tile_cost, PtWorkItem* items, uint32_t* sched_counts, uint32_t* split_tiles, int num_tiles,
+                                    int num_samples, int max_split_tiles, hipStream_t stream);
 hipError_t pt_launch_primary(const PtKernelParams& p, int program_kind, hipStream_t stream);

@@ -175,9 +175,25 @@ __device__ __forceinline__ void test_triangle_from(const TriRec& t, int id, v3 r
     }
 }
 
+// Read-only scene data fetched with a wave-uniform address (triangle and node records, work items) is read through the
+// constant address space: such loads become scalar loads (one fetch per wave into scalar registers) no matter what the
+// kernel stores elsewhere. Nothing a render kernel writes is ever read through these pointers.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef const f32x4 __attribute__((address_space(4))) kf32x4;
+typedef const uint32_t __attribute__((address_space(4))) kuint32;
+struct ScalarView {
+    const kf32x4* p;
+    __device__ __forceinline__ float4 operator[](size_t i) const {
+        const f32x4 v = p[i];
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+};
+__device__ __forceinline__ ScalarView scalar_view(const float4* p) { ScalarView s; s.p = (const kf32x4*)p; return s; }
+
 __device__ __forceinline__ TriRec load_rec(const float4* __restrict__ recs, int i) {
+    const ScalarView k = scalar_view(recs);
     TriRec t;
-    t.a = recs[4 * i]; t.b = recs[4 * i + 1]; t.c = recs[4 * i + 2]; t.d = recs[4 * i + 3];
+    t.a = k[4 * i]; t.b = k[4 * i + 1]; t.c = k[4 * i + 2]; t.d = k[4 * i + 3];
     return t;
 }
 
@@ -328,38 +344,64 @@ __device__ __forceinline__ Hit intersect_bvh(const PtKernelParams& p, v3 ro, v3 
     // Reciprocal direction for the slab tests only (culling arithmetic is not part of the reference's numerics; it
     // only has to be conservative, which the padded boxes and the slack on `limit` guarantee). A zero component is
     // replaced by a tiny one of the same sign: the slab test then degenerates to "origin inside the slab".
-    const float tiny = 1.0e-30f;
+    const float tiny = 1.0e-20f;  // reciprocals stay below 1e20, so centre x reciprocal cannot overflow for any sane coordinate
     const float ix = __builtin_amdgcn_rcpf(__builtin_fabsf(rd.x) > tiny ? rd.x : __builtin_copysignf(tiny, rd.x));
     const float iy = __builtin_amdgcn_rcpf(__builtin_fabsf(rd.y) > tiny ? rd.y : __builtin_copysignf(tiny, rd.y));
     const float iz = __builtin_amdgcn_rcpf(__builtin_fabsf(rd.z) > tiny ? rd.z : __builtin_copysignf(tiny, rd.z));
+    const float ax = __builtin_fabsf(ix), ay = __builtin_fabsf(iy), az = __builtin_fabsf(iz);
+    // origin x reciprocal, subtracted inside the fused multiply-add of each slab
+    const float ox = MOVING ? ro.x * ix : 0.f, oy = MOVING ? ro.y * iy : 0.f, oz = MOVING ? ro.z * iz : 0.f;
     const float4* __restrict__ nodes = reinterpret_cast<const float4*>(MOVING ? p.bvh_nodes_abs : p.bvh_nodes);
     const float4* __restrict__ recs = reinterpret_cast<const float4*>(MOVING ? p.bvh_tris_abs : p.bvh_tris);
-    const float ox = MOVING ? ro.x : 0.f, oy = MOVING ? ro.y : 0.f, oz = MOVING ? ro.z : 0.f;
     uint32_t ref = 0;  // root = internal node 0
     int sp = 0;
     for (;;) {
         if (ref & 0x80000000u) {
+            // A leaf is up to PT_BVH_LEAF_MAX consecutive records; all of them are requested at once (the array is
+            // padded, and a record past the leaf is simply not tested), so a leaf costs one memory latency, not `count`.
             const int first = (int)((ref & 0x7fffffffu) >> 3), count = (int)(ref & 7u) + 1;
-            for (int k = 0; k < count; ++k) {
-                if (MOVING) test_triangle_from<true>(load_rec(recs, first + k), p.bvh_ids[first + k], ro, rd, h);
-                else test_triangle<true>(load_rec(recs, first + k), p.bvh_ids[first + k], rd, h);
+            const TriRec r0 = load_rec(recs, first), r1 = load_rec(recs, first + 1), r2 = load_rec(recs, first + 2),
+                         r3 = load_rec(recs, first + 3);
+            if (MOVING) {
+                test_triangle_from<true>(r0, (int)__float_as_uint(r0.d.w), ro, rd, h);
+                if (count > 1) test_triangle_from<true>(r1, (int)__float_as_uint(r1.d.w), ro, rd, h);
+                if (count > 2) test_triangle_from<true>(r2, (int)__float_as_uint(r2.d.w), ro, rd, h);
+                if (count > 3) test_triangle_from<true>(r3, (int)__float_as_uint(r3.d.w), ro, rd, h);
+            } else {
+                test_triangle<true>(r0, (int)__float_as_uint(r0.d.w), rd, h);
+                if (count > 1) test_triangle<true>(r1, (int)__float_as_uint(r1.d.w), rd, h);
+                if (count > 2) test_triangle<true>(r2, (int)__float_as_uint(r2.d.w), rd, h);
+                if (count > 3) test_triangle<true>(r3, (int)__float_as_uint(r3.d.w), rd, h);
             }
             tri_tests += (unsigned)count;
         } else {
             ++node_visits;
-            const float4 n0 = nodes[4 * (size_t)ref], n1 = nodes[4 * (size_t)ref + 1], n2 = nodes[4 * (size_t)ref + 2],
-                         n3 = nodes[4 * (size_t)ref + 3];
+            const ScalarView kn = scalar_view(nodes + 4 * (size_t)ref);
+            const float4 n0 = kn[0], n1 = kn[1], n2 = kn[2], n3 = kn[3];
             const float limit = h.t * 1.0001f;
-            // left box: n0.xyz = min, (n0.w, n1.x, n1.y) = max; right box: (n1.z, n1.w, n2.x) = min, n2.yzw = max
-            float a, b;
-            a = (n0.x - ox) * ix; b = (n0.w - ox) * ix; float lnear = __builtin_fminf(a, b), lfar = __builtin_fmaxf(a, b);
-            a = (n0.y - oy) * iy; b = (n1.x - oy) * iy; lnear = __builtin_fmaxf(lnear, __builtin_fminf(a, b)); lfar = __builtin_fminf(lfar, __builtin_fmaxf(a, b));
-            a = (n0.z - oz) * iz; b = (n1.y - oz) * iz; lnear = __builtin_fmaxf(lnear, __builtin_fminf(a, b)); lfar = __builtin_fminf(lfar, __builtin_fmaxf(a, b));
-            a = (n1.z - ox) * ix; b = (n2.y - ox) * ix; float rnear = __builtin_fminf(a, b), rfar = __builtin_fmaxf(a, b);
-            a = (n1.w - oy) * iy; b = (n2.z - oy) * iy; rnear = __builtin_fmaxf(rnear, __builtin_fminf(a, b)); rfar = __builtin_fminf(rfar, __builtin_fmaxf(a, b));
-            a = (n2.x - oz) * iz; b = (n2.w - oz) * iz; rnear = __builtin_fmaxf(rnear, __builtin_fminf(a, b)); rfar = __builtin_fminf(rfar, __builtin_fmaxf(a, b));
-            const bool hl = (lnear <= lfar) & (lfar >= 0.0f) & (lnear <= limit);
-            const bool hr = (rnear <= rfar) & (rfar >= 0.0f) & (rnear <= limit);
+            // left box: centre n0.xyz, half extents (n0.w, n1.x, n1.y); right box: centre (n1.z, n1.w, n2.x), half n2.yzw.
+            // Per axis: entry = c*inv - |h*inv|, exit = c*inv + |h*inv| (minus origin*inv for rays with their own origin).
+            // This arithmetic only decides what is skipped; fused multiply-adds are fine here.
+            float m, t;
+            m = n0.w * ax; t = MOVING ? __builtin_fmaf(n0.x, ix, -ox) : n0.x * ix;
+            float lnear = MOVING ? t - m : __builtin_fmaf(n0.x, ix, -m), lfar = MOVING ? t + m : __builtin_fmaf(n0.x, ix, m);
+            m = n1.x * ay; t = MOVING ? __builtin_fmaf(n0.y, iy, -oy) : n0.y * iy;
+            const float lny = MOVING ? t - m : __builtin_fmaf(n0.y, iy, -m), lfy = MOVING ? t + m : __builtin_fmaf(n0.y, iy, m);
+            m = n1.y * az; t = MOVING ? __builtin_fmaf(n0.z, iz, -oz) : n0.z * iz;
+            const float lnz = MOVING ? t - m : __builtin_fmaf(n0.z, iz, -m), lfz = MOVING ? t + m : __builtin_fmaf(n0.z, iz, m);
+            lnear = __builtin_fmaxf(__builtin_fmaxf(lnear, lny), __builtin_fmaxf(lnz, 0.0f));
+            lfar = __builtin_fminf(__builtin_fminf(lfar, lfy), __builtin_fminf(lfz, limit));
+            m = n2.y * ax; t = MOVING ? __builtin_fmaf(n1.z, ix, -ox) : n1.z * ix;
+            float rnear = MOVING ? t - m : __builtin_fmaf(n1.z, ix, -m), rfar = MOVING ? t + m : __builtin_fmaf(n1.z, ix, m);
+            m = n2.z * ay; t = MOVING ? __builtin_fmaf(n1.w, iy, -oy) : n1.w * iy;
+            const float rny = MOVING ? t - m : __builtin_fmaf(n1.w, iy, -m), rfy = MOVING ? t + m : __builtin_fmaf(n1.w, iy, m);
+            m = n2.w * az; t = MOVING ? __builtin_fmaf(n2.x, iz, -oz) : n2.x * iz;
+            const float rnz = MOVING ? t - m : __builtin_fmaf(n2.x, iz, -m), rfz = MOVING ? t + m : __builtin_fmaf(n2.x, iz, m);
+            rnear = __builtin_fmaxf(__builtin_fmaxf(rnear, rny), __builtin_fmaxf(rnz, 0.0f));
+            rfar = __builtin_fminf(__builtin_fminf(rfar, rfy), __builtin_fminf(rfz, limit));
+            // entry clamped to 0 and exit clamped to the current hit distance (with slack, equal distances included)
+            const bool hl = lnear <= lfar;
+            const bool hr = rnear <= rfar;
             const unsigned long long ml = __builtin_amdgcn_ballot_w64(hl), mr = __builtin_amdgcn_ballot_w64(hr);
             const uint32_t lref = __float_as_uint(n3.x), rref = __float_as_uint(n3.y);
             if (ml && mr) {
@@ -447,13 +489,6 @@ __device__ __forceinline__ void shade(Rng& rng, float& energy, v3& rd, v3 N) {
     energy = energy * (diffuse + specular);
 }
 
-// Which pixel tile this block renders. Blocks are handed to CUs in blockIdx order, so `tile_order` (a permutation
-// of the tile numbers, most expensive first, made from the previous dispatch's per-tile cost) keeps the long tiles from
-// starting last. Any permutation gives the same image.
-__device__ __forceinline__ int tile_of_block(const PtKernelParams& p) {
-    return p.tile_order ? (int)p.tile_order[blockIdx.x] : (int)blockIdx.x;
-}
-
 // Shade() of the build-defined diffuse/emissive mode (the reference's live Shade ignores materials; its Lambert and
 // emissive code is only present as comments, fs:269-279, 317-358). material = (r, g, b, e): e > 0 is an emitter of
 // radiance rgb*e that ends the path; otherwise a Lambert surface of albedo rgb: cosine-weighted direction about N from
@@ -524,8 +559,17 @@ __device__ __forceinline__ unsigned __reduce_max_trips(unsigned v) {
 template <int KIND, bool MATERIALS>
 __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKernelParams p) {
     __shared__ uint32_t s_stack[KIND == 2 ? PT_TILE_WAVES : 1][KIND == 2 ? PT_BVH_STACK : 1];
+    // Which tile and which of its samples this block renders. Blocks start in blockIdx order and the work list is sorted
+    // most expensive first, so the long items do not start last; a tile that would be a long serial chain of samples on
+    // one wave is split over several blocks (their samples are folded in order afterwards). Any list that covers every
+    // (tile, sample) once gives the same image.
     int x, y;
-    const int tile = tile_of_block(p);
+    int tile = (int)blockIdx.x, sample_begin = 0, sample_count = p.num_samples, scratch_slot = -1;
+    if (p.items) {
+        if (blockIdx.x >= *(const kuint32*)p.sched_counts) return;  // the grid is sized for the largest possible list
+        const kuint32* item = (const kuint32*)(p.items + blockIdx.x);
+        tile = (int)item[0]; sample_begin = (int)item[1]; sample_count = (int)item[2]; scratch_slot = (int)item[3];
+    }
     const bool in_window = pixel_of_lane(p, tile, x, y);
     const size_t pix = in_window ? ((size_t)y * p.width + x) : 0;
     const v3 ro0 = V(p.ro[0], p.ro[1], p.ro[2]);
@@ -536,11 +580,14 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
     const v3 rd0 = primary_direction(p, rng.fcx, rng.fcy);
 
     float4 prev = make_float4(0.f, 0.f, 0.f, 1.f);
-    if (in_window) prev = reinterpret_cast<const float4*>(p.src)[pix];
+    if (in_window && scratch_slot < 0) prev = reinterpret_cast<const float4*>(p.src)[pix];
     float mr = prev.x, mg = prev.y, mb = prev.z;
+    float4* __restrict__ scratch = nullptr;
+    if (scratch_slot >= 0)
+        scratch = reinterpret_cast<float4*>(p.sample_scratch) + ((size_t)scratch_slot * p.num_samples + sample_begin) * PT_TILE_THREADS + threadIdx.x;
 
-    int remaining = in_window ? p.num_samples : 0;
-    int sample = p.first_sample;
+    int remaining = in_window ? sample_count : 0;
+    int sample = p.first_sample + sample_begin * p.sample_stride;
     unsigned rays = 0;
     unsigned trips = 0;  // loop trips of this wave: trips x 64 lane slots were spent for `rays` useful ones
     unsigned node_visits = 0, tri_tests = 0;  // per WAVE (the BVH walk is wave-uniform): records fetched
@@ -589,7 +636,9 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
             const float ex = energy.x, ey = MATERIALS ? energy.y : energy.x, ez = MATERIALS ? energy.z : energy.x;
             float sr = ex * (omt + 0.5f * t), sg = ey * (omt + 0.7f * t), sb = ez * (omt + 1.0f * t);
             if (MATERIALS) { sr = sr + emitted.x; sg = sg + emitted.y; sb = sb + emitted.z; }
-            if (p.accum_mode == 0) {
+            if (scratch_slot >= 0) {
+                scratch[(size_t)(sample_count - remaining) * PT_TILE_THREADS] = make_float4(sr, sg, sb, 0.f);
+            } else if (p.accum_mode == 0) {
                 const float a = 1.0f / rng.samples;
                 mr = mr + a * (sr - mr);
                 mg = mg + a * (sg - mg);
@@ -604,7 +653,7 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
             rng.sx = 0.0f;
         }
     }
-    if (in_window) {
+    if (in_window && scratch_slot < 0) {
         const float alpha = p.accum_mode == 0 ? 1.0f : prev.w + (float)p.num_samples;
         reinterpret_cast<float4*>(p.dst)[pix] = make_float4(mr, mg, mb, alpha);
     }
@@ -613,7 +662,13 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
     if ((threadIdx.x & 63) == 0 && wave_rays) {
         atomicAdd(&p.counters[0], wave_rays);
         atomicAdd(&p.counters[1], (unsigned long long)wave_trips * 64ull);
-        if (p.tile_cost) atomicAdd(&p.tile_cost[tile], wave_trips);
+        // Scheduling cost of this tile: proportional to the time the wave took. A trip of the all-triangles loop always
+        // costs the same; a trip through the hierarchy costs its node and triangle records plus a fixed share.
+        if (p.tile_cost) {
+            unsigned cost = wave_trips;
+            if (KIND == 2) cost = 8u * wave_trips + __builtin_amdgcn_readfirstlane(node_visits) + __builtin_amdgcn_readfirstlane(tri_tests);
+            atomicAdd(&p.tile_cost[tile], cost);
+        }
         if (KIND >= 2) {
             atomicAdd(&p.counters[2], (unsigned long long)__builtin_amdgcn_readfirstlane(node_visits));
             atomicAdd(&p.counters[3], (unsigned long long)__builtin_amdgcn_readfirstlane(tri_tests));
@@ -730,13 +785,62 @@ __global__ __launch_bounds__(256) void pt_fill_rgba_kernel(float4* img, size_t n
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) img[i] = value;
 }
 
-// Orders the tiles for the next dispatch: most expensive first, by half-octave cost bucket (a counting sort done by
-// one workgroup; slots inside a bucket are handed out atomically, so the result is always a permutation). Also
-// clears the costs for the next accumulation.
-__global__ __launch_bounds__(1024) void pt_schedule_tiles_kernel(uint32_t* __restrict__ cost, uint32_t* __restrict__ order, int n) {
+// Second half of a dispatch for the tiles whose samples were rendered by several blocks: folds the samples a pixel has
+// in the scratch slot into the image in sample order, with the arithmetic of the render kernel (fs:412-415), so the
+// result does not depend on how the samples were distributed.
+__global__ __launch_bounds__(PT_TILE_THREADS) void pt_fold_samples_kernel(const PtKernelParams p) {
+    if (blockIdx.x >= p.sched_counts[1]) return;
+    int x, y;
+    if (!pixel_of_lane(p, (int)p.split_tiles[blockIdx.x], x, y)) return;
+    const size_t pix = (size_t)y * p.width + x;
+    const float4 prev = reinterpret_cast<const float4*>(p.src)[pix];
+    float mr = prev.x, mg = prev.y, mb = prev.z;
+    const float4* __restrict__ scratch = reinterpret_cast<const float4*>(p.sample_scratch) + (size_t)blockIdx.x * p.num_samples * PT_TILE_THREADS + threadIdx.x;
+    int sample = p.first_sample;
+    auto fold = [&](const float4 s) {
+        if (p.accum_mode == 0) {
+            const float a = 1.0f / (float)sample;
+            mr = mr + a * (s.x - mr);
+            mg = mg + a * (s.y - mg);
+            mb = mb + a * (s.z - mb);
+        } else {
+            mr += s.x; mg += s.y; mb += s.z;
+        }
+        sample += p.sample_stride;
+    };
+    // the folds form one dependent chain; the loads do not, so they are issued eight at a time ahead of it
+    int k = 0;
+    for (; k + 8 <= p.num_samples; k += 8) {
+        float4 s[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] = scratch[(size_t)(k + j) * PT_TILE_THREADS];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fold(s[j]);
+    }
+    for (; k < p.num_samples; ++k) fold(scratch[(size_t)k * PT_TILE_THREADS]);
+    const float alpha = p.accum_mode == 0 ? 1.0f : prev.w + (float)p.num_samples;
+    reinterpret_cast<float4*>(p.dst)[pix] = make_float4(mr, mg, mb, alpha);
+}
+
+// Builds the work list of the next dispatch from the per-tile costs the previous one measured (loop trips per tile).
+// granule = total cost / max_split + 1: a tile above it is split into ceil(cost / granule) items of equal sample counts
+// (at most num_samples), so the extra items and the split tiles both stay below max_split. Items are placed most
+// expensive first by half-octave bucket of their cost (a counting sort done by one workgroup; positions inside a bucket
+// are handed out atomically, so the list is always a complete cover). Also clears the costs for the next accumulation.
+__global__ __launch_bounds__(1024) void pt_schedule_items_kernel(uint32_t* __restrict__ cost, PtWorkItem* __restrict__ items,
+                                                                 uint32_t* __restrict__ counts, uint32_t* __restrict__ split_tiles, int n,
+                                                                 int num_samples, int max_split) {
     __shared__ uint32_t hist[64], start[64];
+    __shared__ unsigned long long total;
+    __shared__ uint32_t num_split;
     if (threadIdx.x < 64) hist[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { total = 0; num_split = 0; }
     __syncthreads();
+    unsigned long long mine = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) mine += cost[i];
+    atomicAdd(&total, mine);
+    __syncthreads();
+    const unsigned long long granule = max_split > 0 ? total / (unsigned long long)max_split + 1ull : ~0ull;
     auto bucket = [](uint32_t c) -> int {
         if (c < 2) return (int)c;
         const int lg = 31 - __builtin_clz(c);
@@ -744,23 +848,50 @@ __global__ __launch_bounds__(1024) void pt_schedule_tiles_kernel(uint32_t* __res
         const int b = 2 * lg + half;
         return b > 63 ? 63 : b;
     };
-    for (int i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&hist[bucket(cost[i])], 1u);
+    // pieces of a tile and samples per piece
+    auto split = [granule, num_samples](uint32_t c, int& per_piece) -> int {
+        unsigned long long k = ((unsigned long long)c + granule - 1) / granule;
+        if (k < 1) k = 1;
+        if (k > (unsigned long long)num_samples) k = (unsigned long long)num_samples;
+        per_piece = (num_samples + (int)k - 1) / (int)k;
+        return (num_samples + per_piece - 1) / per_piece;
+    };
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        int per_piece;
+        const int k = split(cost[i], per_piece);
+        atomicAdd(&hist[bucket(cost[i] / (uint32_t)k)], (uint32_t)k);
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t acc = 0;
         for (int b = 63; b >= 0; --b) { start[b] = acc; acc += hist[b]; }
+        counts[0] = acc;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const uint32_t slot = atomicAdd(&start[bucket(cost[i])], 1u);
-        order[slot] = (uint32_t)i;
+        int per_piece;
+        const int k = split(cost[i], per_piece);
+        const uint32_t first = atomicAdd(&start[bucket(cost[i] / (uint32_t)k)], (uint32_t)k);
+        int slot = -1;
+        if (k > 1) {
+            slot = (int)atomicAdd(&num_split, 1u);
+            split_tiles[slot] = (uint32_t)i;
+        }
+        for (int j = 0; j < k; ++j) {
+            PtWorkItem it;
+            it.tile = (uint32_t)i;
+            it.sample_begin = (uint32_t)(j * per_piece);
+            it.sample_count = (uint32_t)(num_samples - j * per_piece < per_piece ? num_samples - j * per_piece : per_piece);
+            it.scratch_slot = slot;
+            items[first + (uint32_t)j] = it;
+        }
     }
     __syncthreads();
+    if (threadIdx.x == 0) counts[1] = num_split;
     for (int i = threadIdx.x; i < n; i += blockDim.x) cost[i] = 0;
 }
 
 int window_tiles(const PtKernelParams& p) { return PT_TILES_ACROSS(p.win_w) * PT_TILES_ACROSS(p.win_h); }
-
 }  // namespace
 
 hipError_t pt_launch_prepare_triangles(const float* vertices, const uint32_t* indices, int32_t num_triangles,
@@ -788,15 +919,17 @@ hipError_t pt_launch_present(const float* img, size_t num_pixels, uint32_t* out_
     return hipGetLastError();
 }
 
-hipError_t pt_launch_schedule_tiles(uint32_t* tile_cost, uint32_t* tile_order, int num_tiles, hipStream_t stream) {
+hipError_t pt_launch_schedule_items(uint32_t* tile_cost, PtWorkItem* items, uint32_t* sched_counts, uint32_t* split_tiles, int num_tiles,
+                                    int num_samples, int max_split_tiles, hipStream_t stream) {
     if (num_tiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(pt_schedule_tiles_kernel, dim3(1), dim3(1024), 0, stream, tile_cost, tile_order, num_tiles);
+    hipLaunchKernelGGL(pt_schedule_items_kernel, dim3(1), dim3(1024), 0, stream, tile_cost, items, sched_counts, split_tiles, num_tiles,
+                       num_samples, max_split_tiles);
     return hipGetLastError();
 }
 
 hipError_t pt_launch_render(const PtKernelParams& p, int program_kind, hipStream_t stream) {
     if (p.win_w <= 0 || p.win_h <= 0 || p.num_samples <= 0) return hipSuccess;
-    const dim3 grid(window_tiles(p)), block(PT_TILE_THREADS);
+    const dim3 grid(p.items ? p.max_items : window_tiles(p)), block(PT_TILE_THREADS);
     if (program_kind == 0) hipLaunchKernelGGL((pt_render_kernel<0, false>), grid, block, 0, stream, p);
     else if (p.shading_mode == 1) {
         if (p.bvh_nodes_abs) hipLaunchKernelGGL((pt_render_kernel<2, true>), grid, block, 0, stream, p);
@@ -805,6 +938,8 @@ hipError_t pt_launch_render(const PtKernelParams& p, int program_kind, hipStream
     else if (p.bvh_nodes) hipLaunchKernelGGL((pt_render_kernel<2, false>), grid, block, 0, stream, p);
     else if (p.cull) hipLaunchKernelGGL((pt_render_kernel<3, false>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL((pt_render_kernel<1, false>), grid, block, 0, stream, p);
+    if (p.items && p.max_split_tiles > 0 && p.num_samples > 1)
+        hipLaunchKernelGGL(pt_fold_samples_kernel, dim3(p.max_split_tiles), dim3(PT_TILE_THREADS), 0, stream, p);
     return hipGetLastError();
 }
 

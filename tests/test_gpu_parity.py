@@ -172,6 +172,49 @@ def test_materials_mode_state_errors(tracer):
     t.program_destroy(prog)
 
 
+@pytest.mark.parametrize("name", ["monkey_mesh_128", "world_128", "cornell_geo_128", "cornell_materials_128"])
+def test_split_tiles_fold_in_sample_order(tracer, name):
+    """From the second dispatch of a window on, expensive tiles are rendered by several blocks (each a range of the
+    samples, parked in scratch memory) and folded in sample order afterwards. The image must not change by a bit:
+    against the golden in MEAN mode, and against the unsplit first dispatch in SUM mode with a sample stride."""
+    fx = load_case(name)
+    t = tracer
+    prog = setup_case(t, fx)
+    t.dispatch(1, 16, 1)            # no costs known yet: one block per tile
+    t.finish()
+    first = t.readback()
+    for _ in range(2):              # costs known: at 128x128 every tile that hits something is split
+        t.target_clear()
+        t.dispatch(1, 16, 1)
+        t.finish()
+        img = t.readback()
+        assert n_bit_mismatch(img, first) == 0
+    assert n_bit_mismatch(img[..., :3], fx["lp_rgb_16"]) == 0
+    # continue an image (previous value read by the fold pass), odd sample count
+    t.dispatch(17, 5, 1)
+    t.finish()
+    cont = t.readback()
+    t.set_accum_mode(1)
+    t.target_clear()
+    t.dispatch(2, 7, 3)
+    t.finish()
+    split_sum = t.readback()
+    t.set_window(0, 0, 127, 128)    # a new window forgets the costs: unsplit again
+    t.target_clear()
+    t.dispatch(2, 7, 3)
+    t.finish()
+    plain_sum = t.readback()
+    assert n_bit_mismatch(split_sum[:, :127], plain_sum[:, :127]) == 0
+    assert np.all(split_sum[..., 3] == 7.0)
+    t.set_window()
+    t.set_accum_mode(0)
+    t.target_clear()
+    t.dispatch(1, 21, 1)
+    t.finish()
+    assert n_bit_mismatch(t.readback(), cont) == 0
+    t.program_destroy(prog)
+
+
 def test_ray_count_matches_oracle(tracer):
     fx = load_case("monkey_mesh_128")
     t = tracer
