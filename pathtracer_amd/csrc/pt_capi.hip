@@ -98,6 +98,9 @@ struct PtContext {
     float split_factor = -1.f;            // < 0: chosen per kernel family, see pt_dispatch
     int32_t sched_win[4] = {-1, -1, -1, -1};  // window the costs were measured for
     bool sched_have_cost = false;
+    // the work list built last and what it was built for; reused while nothing it depends on changes
+    bool list_valid = false;
+    int32_t list_samples = 0, list_max_split = 0, list_age = 0;
     int sched_mode = 2;             // 0 raster order, 1 cost-ordered tiles, 2 cost-ordered items with heavy tiles split by samples
 
     // uniforms
@@ -117,6 +120,7 @@ struct PtContext {
 
 namespace {
 
+constexpr size_t kCounterBytes = (size_t)PT_COUNTER_SLOTS * PT_COUNTER_STRIDE * sizeof(unsigned long long);
 constexpr int PT_MAX_SPLIT_FACTOR = 8;  // arrays of the scheduler are sized for this many split tiles per wave slot
 
 PtStatus bind(PtContext* ctx) {
@@ -209,6 +213,7 @@ PtStatus ensure_records(PtContext* ctx) {
     }
     memcpy(ctx->records_ro, ro, sizeof ctx->records_ro);
     ctx->records_valid = true;
+    ctx->list_valid = false;  // new mesh or camera position: the tile costs will change
     return PT_OK;
 }
 
@@ -320,8 +325,8 @@ PtStatus pt_create(int32_t device, PtContext** out_ctx) {
     PT_REQUIRE(ctx != nullptr, PT_ERR_HIP, "out of host memory");
     ctx->device = device;
     hipError_t err = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
-    if (err == hipSuccess) err = hipMalloc(&ctx->d_counters, 4 * sizeof(unsigned long long));
-    if (err == hipSuccess) err = hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(unsigned long long), ctx->own_stream);
+    if (err == hipSuccess) err = hipMalloc(&ctx->d_counters, kCounterBytes);
+    if (err == hipSuccess) err = hipMemsetAsync(ctx->d_counters, 0, kCounterBytes, ctx->own_stream);
     if (err == hipSuccess) err = hipStreamSynchronize(ctx->own_stream);
     if (err == hipSuccess) err = hipMalloc(&ctx->d_spheres, 40 * sizeof(float));
     if (err == hipSuccess) err = hipEventCreate(&ctx->ev_start);
@@ -689,8 +694,19 @@ PtStatus pt_dispatch(PtContext* ctx, int32_t first_sample, int32_t num_samples, 
                 PT_HIP_TRY(hipMalloc(&ctx->d_sample_scratch, slot_bytes * (size_t)max_split));
                 ctx->sample_scratch_bytes = slot_bytes * (size_t)max_split;
             }
-            PT_HIP_TRY(pt_launch_schedule_items(ctx->d_tile_cost, ctx->d_items, ctx->d_sched_counts, ctx->d_split_tiles, tiles, num_samples,
-                                                max_split, ctx->stream));
+            // The list stays valid for any later dispatch of the same window and sample count (it only has to cover
+            // every tile and sample once); it is rebuilt from the costs gathered meanwhile every 16th dispatch and after
+            // scene or camera changes, so a frame loop does not pay for the scheduler on every frame.
+            const bool reuse = ctx->list_valid && ctx->list_samples == num_samples && ctx->list_max_split == max_split && ctx->list_age < 16;
+            if (!reuse) {
+                PT_HIP_TRY(pt_launch_schedule_items(ctx->d_tile_cost, ctx->d_items, ctx->d_sched_counts, ctx->d_split_tiles, tiles, num_samples,
+                                                    max_split, ctx->stream));
+                ctx->list_valid = true;
+                ctx->list_samples = num_samples;
+                ctx->list_max_split = max_split;
+                ctx->list_age = 0;
+            }
+            ++ctx->list_age;
             p.items = ctx->d_items;
             p.sched_counts = ctx->d_sched_counts;
             p.split_tiles = ctx->d_split_tiles;
@@ -700,6 +716,7 @@ PtStatus pt_dispatch(PtContext* ctx, int32_t first_sample, int32_t num_samples, 
         } else {
             PT_HIP_TRY(hipMemsetAsync(ctx->d_tile_cost, 0, (size_t)tiles * sizeof(uint32_t), ctx->stream));
             p.items = nullptr;
+            ctx->list_valid = false;
         }
         p.tile_cost = ctx->d_tile_cost;
         memcpy(ctx->sched_win, ctx->win, sizeof ctx->win);
@@ -796,9 +813,12 @@ PtStatus pt_get_stats(PtContext* ctx, PtStats* out) {
     PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
     s = collect_timing(ctx);
     if (s != PT_OK) return s;
-    unsigned long long c[4] = {0, 0, 0, 0};
-    PT_HIP_TRY(hipMemcpyAsync(c, ctx->d_counters, sizeof c, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<unsigned long long> slots((size_t)PT_COUNTER_SLOTS * PT_COUNTER_STRIDE);
+    PT_HIP_TRY(hipMemcpyAsync(slots.data(), ctx->d_counters, kCounterBytes, hipMemcpyDeviceToHost, ctx->stream));
     PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    unsigned long long c[4] = {0, 0, 0, 0};
+    for (size_t k = 0; k < PT_COUNTER_SLOTS; ++k)
+        for (int j = 0; j < 4; ++j) c[j] += slots[k * PT_COUNTER_STRIDE + j];
     out->rays = c[0];
     out->samples = ctx->samples;
     out->lane_slots = c[1];
@@ -816,7 +836,7 @@ PtStatus pt_reset_stats(PtContext* ctx) {
     PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
     s = collect_timing(ctx);
     if (s != PT_OK) return s;
-    PT_HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(unsigned long long), ctx->stream));
+    PT_HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, kCounterBytes, ctx->stream));
     PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->samples = 0;
     ctx->dispatches = 0;

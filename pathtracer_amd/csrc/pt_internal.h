@@ -36,6 +36,11 @@ struct PtTriRecordLayout {
 #define PT_BVH_STACK 96
 #define PT_BVH_AUTO_MIN_TRIANGLES 128
 
+// Statistics counters are spread over many cache lines: every wave adds to them once, and with one address those
+// additions queue up behind each other in L2 (measured: 32,400 short waves took 0.83 ms for 0.12 ms of work).
+#define PT_COUNTER_SLOTS 1024
+#define PT_COUNTER_STRIDE 16  // 64-bit words per slot = one 128-byte line
+
 struct PtBvhBuild {
     int32_t num_triangles;
     float scene_scale;            // largest absolute vertex coordinate (host-computed at upload)
@@ -118,7 +123,8 @@ struct PtKernelParams {
     const float* spheres;               // 10 x (cx, cy, cz, r)
     const float* src;                   // RGBA32F image read (previous result)
     float* dst;                         // RGBA32F image written
-    unsigned long long* counters;       // [0] rays, [1] lane slots spent (wave loop trips x 64)
+    unsigned long long* counters;       // PT_COUNTER_SLOTS x PT_COUNTER_STRIDE: per slot [0] rays, [1] lane slots spent (wave loop trips x 64),
+                                        // [2] node records, [3] triangle records fetched by the hierarchy walk
     const PtWorkItem* items;            // work list (block -> item), or null = block b renders tile b with all samples
     const uint32_t* sched_counts;       // [0] number of items, [1] number of split tiles (device scalars written by the scheduler)
     const uint32_t* split_tiles;        // scratch slot -> tile

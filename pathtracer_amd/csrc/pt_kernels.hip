@@ -660,8 +660,9 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
     const unsigned long long wave_rays = wave_sum(rays);
     const unsigned wave_trips = __builtin_amdgcn_readfirstlane(__reduce_max_trips(trips));
     if ((threadIdx.x & 63) == 0 && wave_rays) {
-        atomicAdd(&p.counters[0], wave_rays);
-        atomicAdd(&p.counters[1], (unsigned long long)wave_trips * 64ull);
+        unsigned long long* counters = p.counters + (size_t)(blockIdx.x % PT_COUNTER_SLOTS) * PT_COUNTER_STRIDE;
+        atomicAdd(&counters[0], wave_rays);
+        atomicAdd(&counters[1], (unsigned long long)wave_trips * 64ull);
         // Scheduling cost of this tile: proportional to the time the wave took. A trip of the all-triangles loop always
         // costs the same; a trip through the hierarchy costs its node and triangle records plus a fixed share.
         if (p.tile_cost) {
@@ -670,8 +671,8 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
             atomicAdd(&p.tile_cost[tile], cost);
         }
         if (KIND >= 2) {
-            atomicAdd(&p.counters[2], (unsigned long long)__builtin_amdgcn_readfirstlane(node_visits));
-            atomicAdd(&p.counters[3], (unsigned long long)__builtin_amdgcn_readfirstlane(tri_tests));
+            atomicAdd(&counters[2], (unsigned long long)__builtin_amdgcn_readfirstlane(node_visits));
+            atomicAdd(&counters[3], (unsigned long long)__builtin_amdgcn_readfirstlane(tri_tests));
         }
     }
 }
