@@ -164,19 +164,25 @@ def main():
         big.upload(t2)
         t2.target_create(big.width, big.height)
         t2.enable_timing(True)
-        t2.dispatch(1, 2, 1)
+        for _ in range(2):          # warm-up: the second dispatch already runs from a work list built on measured tile costs
+            t2.target_clear()
+            t2.dispatch(1, 16, 1)
         t2.finish()
         t2.reset_stats()
-        t2.target_clear()
-        t2.dispatch(1, 16, 1)
+        for _ in range(3):
+            t2.target_clear()
+            t2.dispatch(1, 16, 1)
         t2.finish()
         s2 = t2.stats()
-        large = {"workload": f"instanced suzanne x254, {big.num_triangles} triangles, {big.width}x{big.height}, 16 spp, device LBVH",
+        s2 = dict(s2, last_dispatch_ms=s2["total_dispatch_ms"] / s2["dispatches"], rays=s2["rays"] / s2["dispatches"],
+                  samples=s2["samples"] / s2["dispatches"], lane_slots=s2["lane_slots"] / s2["dispatches"],
+                  bvh_node_fetches=s2["bvh_node_fetches"] / s2["dispatches"], bvh_triangle_fetches=s2["bvh_triangle_fetches"] / s2["dispatches"])
+        large = {"workload": f"instanced suzanne x254, {big.num_triangles} triangles, {big.width}x{big.height}, 16 spp per dispatch, device LBVH (mean of 3 dispatches)",
                  "Mrays_per_s": s2["rays"] / s2["last_dispatch_ms"] * 1e-3, "kernel_ms": s2["last_dispatch_ms"],
                  "rays_per_sample": s2["rays"] / s2["samples"],
                  "node_records_per_wave_ray": s2["bvh_node_fetches"] * 64 / max(1, s2["lane_slots"]),
                  "triangle_records_per_wave_ray": s2["bvh_triangle_fetches"] * 64 / max(1, s2["lane_slots"]),
-                 "fetched_GB_per_s": (s2["bvh_node_fetches"] * 64 + s2["bvh_triangle_fetches"] * 68) / (s2["last_dispatch_ms"] * 1e-3) * 1e-9,
+                 "fetched_GB_per_s": (s2["bvh_node_fetches"] * 64 + s2["bvh_triangle_fetches"] * 64) / (s2["last_dispatch_ms"] * 1e-3) * 1e-9,
                  "brute_force_equivalent_TFLOP_per_s": s2["rays"] * FLOP_PER_TRI_TEST * big.num_triangles / (s2["last_dispatch_ms"] * 1e-3) * 1e-12}
         t2.close()
 
@@ -222,20 +228,21 @@ def main():
         if st["bvh_node_fetches"] > 0:
             # LBVH traversal: the dominant cost is fetching node and triangle records (64 B each, once per wave);
             # they come from L2 / Infinity Cache, priced here against the HBM peak as the outermost bound
-            fetched = (st["bvh_node_fetches"] * 64 + st["bvh_triangle_fetches"] * 68) / max(1, st["dispatches"])
+            fetched = (st["bvh_node_fetches"] * 64 + st["bvh_triangle_fetches"] * 64) / max(1, st["dispatches"])
             gbs = fetched / (kernel_ms * 1e-3) * 1e-9
             out["config"]["workload"] = out["config"]["workload"].replace("brute-force closest hit", "device LBVH, wave-coherent traversal")
             out["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": None,
                                "kernel": "pt_render_kernel<bvh>", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": fetched,
                                "brute_force_equivalent_TFLOP_per_s": achieved,
-                               "note": "bytes = node records x 64 + triangle records x 68, counted in-kernel once per wave fetch; "
+                               "note": "bytes = (node records + triangle records) x 64, counted in-kernel once per wave fetch; "
                                        "latency-bound pointer chasing served by L2/Infinity Cache, far below the HBM roof"}
         if large:
             out["large_scene"] = large
-        # HBM bytes per launch from rocprofv3 PMC passes of this same workload (profiles/r01_pmc_cornell.json: FETCH_SIZE
-        # doubled as the gfx950 correction prescribes, plus WRITE_SIZE); counters cannot be read from inside this run
+        # HBM bytes per launch from rocprofv3 PMC passes of this same workload (profiles/r01_pmc_cornell_b.json: FETCH_SIZE
+        # 18304.6 KB doubled as the gfx950 correction prescribes, plus WRITE_SIZE 35437.5 KB); counters cannot be read
+        # from inside this run
         if args.workload == "cornell" and (W, H, spp) == (1920, 1080, 256):
-            out["roofline"]["traffic"] = 33326976.0 + 35251200.0
+            out["roofline"]["traffic"] = 37487744.0 + 36288000.0
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, spp)
         print(json.dumps(out), flush=True)

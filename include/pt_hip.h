@@ -56,11 +56,12 @@ typedef enum PtNormalMode {
 
 /* How the closest mesh hit is searched. Results are identical in every mode (same triangle ids, same distances). */
 typedef enum PtAccelMode {
-    PT_ACCEL_AUTO = 0,  /* the fastest measured choice: the plain loop for small meshes, the LBVH (once built) above 128 triangles */
+    PT_ACCEL_AUTO = 0,  /* the fastest measured choice: the plain loop for small meshes, the LBVH (once built) above 48 triangles
+                           (128 in PT_SHADE_MATERIALS) */
     PT_ACCEL_BRUTE = 1, /* the shader's own loop over all triangles in index order, pathtracing.fs:129 */
     PT_ACCEL_BVH = 2,   /* require the LBVH: pt_dispatch fails with PT_ERR_STATE when none is built */
     PT_ACCEL_CULL = 3   /* all-triangles loop that skips, 64 triangles at a time, those no ray of the wave can reach;
-                           exact, but measured slower than BRUTE (36 triangles) and BVH (>= 968): kept for experiments */
+                           exact, but measured slower than BRUTE (36 triangles) and BVH (>= 64): kept for experiments */
 } PtAccelMode;
 
 /* How a dispatch folds a sample into the target. */

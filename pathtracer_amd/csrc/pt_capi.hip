@@ -101,6 +101,8 @@ struct PtContext {
     // the work list built last and what it was built for; reused while nothing it depends on changes
     bool list_valid = false;
     int32_t list_samples = 0, list_max_split = 0, list_age = 0;
+    int64_t cost_samples = 0;   // samples per pixel behind the costs gathered since the list was built
+    int64_t list_basis = 0;     // samples per pixel behind the costs the list was built from
     int sched_mode = 2;             // 0 raster order, 1 cost-ordered tiles, 2 cost-ordered items with heavy tiles split by samples
 
     // uniforms
@@ -248,11 +250,11 @@ PtStatus fill_params(PtContext* ctx, PtKernelParams* p, const Program** prog_out
         p->gnormals = ctx->d_gnormals;
         PT_REQUIRE(ctx->accel_mode != PT_ACCEL_BVH || ctx->bvh_built, PT_ERR_STATE, "PT_ACCEL_BVH but no BVH: call pt_build_accel first");
         // the hierarchy covers the whole mesh, so it serves only when every uploaded triangle is traced
-        // and in AUTO mode only when the mesh is big enough for the walk to beat the plain loop (36 triangles: the
-        // loop is 15 % faster; 968: the BVH is 6x faster)
+        // and in AUTO mode only when the mesh is big enough for the walk to beat the plain loop
         const bool use_bvh = ctx->bvh_built && ctx->accel_mode != PT_ACCEL_BRUTE && ctx->accel_mode != PT_ACCEL_CULL &&
                              u.num_triangles == ctx->num_triangles &&
-                             (ctx->accel_mode == PT_ACCEL_BVH || u.num_triangles > PT_BVH_AUTO_MIN_TRIANGLES);
+                             (ctx->accel_mode == PT_ACCEL_BVH ||
+                              u.num_triangles > (ctx->shading_mode == PT_SHADE_MATERIALS ? PT_BVH_AUTO_MIN_TRIANGLES_MOVING : PT_BVH_AUTO_MIN_TRIANGLES));
         PT_REQUIRE(use_bvh || ctx->accel_mode != PT_ACCEL_BVH, PT_ERR_STATE, "the BVH covers all %d triangles but u_NumTriangles = %d",
                    ctx->num_triangles, u.num_triangles);
         p->shading_mode = (int32_t)ctx->shading_mode;
@@ -695,9 +697,13 @@ PtStatus pt_dispatch(PtContext* ctx, int32_t first_sample, int32_t num_samples, 
                 ctx->sample_scratch_bytes = slot_bytes * (size_t)max_split;
             }
             // The list stays valid for any later dispatch of the same window and sample count (it only has to cover
-            // every tile and sample once); it is rebuilt from the costs gathered meanwhile every 16th dispatch and after
-            // scene or camera changes, so a frame loop does not pay for the scheduler on every frame.
-            const bool reuse = ctx->list_valid && ctx->list_samples == num_samples && ctx->list_max_split == max_split && ctx->list_age < 16;
+            // every tile and sample once), so a frame loop does not pay for the scheduler on every frame. It is rebuilt
+            // after scene or camera changes, every 16th dispatch, and as soon as the costs gathered since rest on twice as
+            // many samples as the ones it was built from: one sample per pixel is a noisy estimate of a tile's cost, and
+            // a list built from it left the truly long tiles unsplit (1M triangles, 16 spp: 11.0 ms against 7.6 ms with
+            // costs from 16 samples).
+            const bool reuse = ctx->list_valid && ctx->list_samples == num_samples && ctx->list_max_split == max_split &&
+                               ctx->list_age < 16 && ctx->cost_samples < 2 * ctx->list_basis;
             if (!reuse) {
                 PT_HIP_TRY(pt_launch_schedule_items(ctx->d_tile_cost, ctx->d_items, ctx->d_sched_counts, ctx->d_split_tiles, tiles, num_samples,
                                                     max_split, ctx->stream));
@@ -705,6 +711,8 @@ PtStatus pt_dispatch(PtContext* ctx, int32_t first_sample, int32_t num_samples, 
                 ctx->list_samples = num_samples;
                 ctx->list_max_split = max_split;
                 ctx->list_age = 0;
+                ctx->list_basis = ctx->cost_samples > 0 ? ctx->cost_samples : 1;
+                ctx->cost_samples = 0;
             }
             ++ctx->list_age;
             p.items = ctx->d_items;
@@ -717,8 +725,10 @@ PtStatus pt_dispatch(PtContext* ctx, int32_t first_sample, int32_t num_samples, 
             PT_HIP_TRY(hipMemsetAsync(ctx->d_tile_cost, 0, (size_t)tiles * sizeof(uint32_t), ctx->stream));
             p.items = nullptr;
             ctx->list_valid = false;
+            ctx->cost_samples = 0;
         }
         p.tile_cost = ctx->d_tile_cost;
+        ctx->cost_samples += num_samples;
         memcpy(ctx->sched_win, ctx->win, sizeof ctx->win);
         ctx->sched_have_cost = true;
     }

@@ -125,16 +125,30 @@ template <bool ANY_ORDER>
 __device__ __forceinline__ void test_triangle(const TriRec& t, int id, v3 rd, Hit& h) {
     const v3 e1 = V(t.a.x, t.a.y, t.a.z);
     const v3 e2 = V(t.a.w, t.b.x, t.b.y);
+#ifdef PT_V_VFIRST
+    // v does not depend on the cross product: computed first, and when no lane has v >= 0 nothing else is needed
+    const v3 r0 = V(t.c.y, t.c.z, t.c.w);
+    const float v0 = dot3(rd, r0);
+    if (!__builtin_amdgcn_ballot_w64(v0 >= 0.0f)) return;
+#endif
     const v3 q = cross3(rd, e2);
     const float det = dot3(e1, q);
 #ifndef PT_V_NO_DETSKIP
     // wave-uniform skip: when no lane sees the front of the triangle the two remaining dot products are not needed
+#ifdef PT_V_VFIRST
+    if (!__builtin_amdgcn_ballot_w64((det >= 0.0001f) & (v0 >= 0.0f))) return;
+#else
     if (!__builtin_amdgcn_ballot_w64(det >= 0.0001f)) return;
 #endif
+#endif
     const v3 ap = V(t.b.z, t.b.w, t.c.x);
-    const v3 r = V(t.c.y, t.c.z, t.c.w);
     const float u = dot3(ap, q);
+#ifdef PT_V_VFIRST
+    const float v = v0;
+#else
+    const v3 r = V(t.c.y, t.c.z, t.c.w);
     const float v = dot3(rd, r);
+#endif
     // fs:142,151. "u <= det" is implied by the other three (v >= 0 makes fl(u+v) >= u), so it is not evaluated.
     const bool inside = (det >= 0.0001f) & (u >= 0.0f) & (v >= 0.0f) & ((u + v) <= det);
     if (inside) {

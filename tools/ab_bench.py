@@ -15,8 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 VARIANTS = {
-    "waves4": [],
-    "waves1": ["-DPT_TILE_WAVES=1"],
+    "base": [],
+    "vfirst": ["-DPT_V_VFIRST"],
 }
 
 
