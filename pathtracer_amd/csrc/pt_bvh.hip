@@ -183,8 +183,10 @@ __global__ __launch_bounds__(256) void bvh_emit_nodes(const uint32_t* __restrict
 
 // Triangle records and ids in sorted (leaf) order; the tail is padded with all-zero records like the unsorted array.
 // The id also goes into the record's last (unused) word, so that a leaf needs no second fetch.
+// drop_unreachable: records whose e2r (first word of the last quarter) is not positive can never be hit by a ray from
+// the shared origin (t = e2r / det with det > 0); they are stored as zeros, which fail the test at its first comparison.
 __global__ __launch_bounds__(256) void bvh_gather_records(const uint32_t* __restrict__ order, const float4* __restrict__ tris, int n,
-                                                          float4* __restrict__ sorted_tris, int* __restrict__ sorted_ids) {
+                                                          float4* __restrict__ sorted_tris, int* __restrict__ sorted_ids, bool drop_unreachable) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n + PT_TRI_PAD) return;
     if (k < n) {
@@ -193,6 +195,8 @@ __global__ __launch_bounds__(256) void bvh_gather_records(const uint32_t* __rest
         float4 last = tris[4 * (size_t)id + 3];
         last.w = __uint_as_float(id);
         sorted_tris[4 * (size_t)k + 3] = last;
+        if (drop_unreachable && !(last.x > 0.0f))
+            for (int q = 0; q < 3; ++q) sorted_tris[4 * (size_t)k + q] = make_float4(0.f, 0.f, 0.f, 0.f);
         sorted_ids[k] = (int)id;
     } else {
         for (int q = 0; q < 4; ++q) sorted_tris[4 * (size_t)k + q] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -255,8 +259,8 @@ hipError_t pt_bvh_emit(const PtBvhBuild& b, const float ro[3], const float* tris
                            0.0f, 0.0f, 4.0e-6f * b.scene_scale, b.nodes_abs);
     }
     hipLaunchKernelGGL(bvh_gather_records, grid_for(n + PT_TRI_PAD), dim3(256), 0, stream, b.order, reinterpret_cast<const float4*>(tris_abs), n,
-                       reinterpret_cast<float4*>(b.sorted_tris_abs), b.sorted_ids);
+                       reinterpret_cast<float4*>(b.sorted_tris_abs), b.sorted_ids, false);
     hipLaunchKernelGGL(bvh_gather_records, grid_for(n + PT_TRI_PAD), dim3(256), 0, stream, b.order, reinterpret_cast<const float4*>(tris), n,
-                       reinterpret_cast<float4*>(b.sorted_tris), b.sorted_ids);
+                       reinterpret_cast<float4*>(b.sorted_tris), b.sorted_ids, true);
     return hipGetLastError();
 }

@@ -60,6 +60,8 @@ struct PtContext {
     uint32_t* d_indices = nullptr;  // raw upload
     int32_t num_vertices = 0, num_triangles = 0;
     float* d_tris = nullptr;        // SoA records, rebuilt when the mesh or the camera position changes
+    float* d_tris_live = nullptr;   // the records a camera ray can hit at all, compacted (all-triangles loop)
+    uint32_t* d_live_count = nullptr;
     float* d_vnormals = nullptr;
     float* d_gnormals = nullptr;
     float* d_cull = nullptr;
@@ -96,6 +98,7 @@ struct PtContext {
     size_t sample_scratch_bytes = 0;
     int32_t wave_slots = 0;               // waves the device holds at once (CUs x 4 SIMDs x 8)
     float split_factor = -1.f;            // < 0: chosen per kernel family, see pt_dispatch
+    bool keep_unreachable = false;        // PT_KEEP_UNREACHABLE=1: the loop walks all records (to measure the compaction)
     int32_t sched_win[4] = {-1, -1, -1, -1};  // window the costs were measured for
     bool sched_have_cost = false;
     // the work list built last and what it was built for; reused while nothing it depends on changes
@@ -186,7 +189,9 @@ void free_bvh(PtContext* ctx) {
 
 void free_mesh(PtContext* ctx) {
     free_bvh(ctx);
-    float** f[] = {&ctx->d_vertices, &ctx->d_tris, &ctx->d_vnormals, &ctx->d_gnormals, &ctx->d_cull, &ctx->d_tris_abs};
+    float** f[] = {&ctx->d_vertices, &ctx->d_tris, &ctx->d_vnormals, &ctx->d_gnormals, &ctx->d_cull, &ctx->d_tris_abs, &ctx->d_tris_live};
+    if (ctx->d_live_count) (void)hipFree(ctx->d_live_count);
+    ctx->d_live_count = nullptr;
     for (float** q : f) {
         if (*q) (void)hipFree(*q);
         *q = nullptr;
@@ -207,6 +212,7 @@ PtStatus ensure_records(PtContext* ctx) {
     if (ctx->records_valid && memcmp(ro, ctx->records_ro, sizeof ctx->records_ro) == 0) return PT_OK;
     PT_HIP_TRY(pt_launch_prepare_triangles(ctx->d_vertices, ctx->d_indices, ctx->num_triangles, ro, ctx->d_tris,
                                            ctx->d_vnormals, ctx->d_gnormals, ctx->d_cull, ctx->d_tris_abs, ctx->stream));
+    PT_HIP_TRY(pt_launch_compact_triangles(ctx->d_tris, ctx->num_triangles, ctx->d_tris_live, ctx->d_live_count, ctx->stream));
     // the BVH's boxes and leaf-order records are expressed relative to the ray origin too
     if (ctx->bvh_built) {
         // absolute-box variant: its padding scales with the largest coordinate a ray origin or a box can have
@@ -246,6 +252,11 @@ PtStatus fill_params(PtContext* ctx, PtKernelParams* p, const Program** prog_out
             if (s != PT_OK) return s;
         }
         p->tris = ctx->d_tris;
+        // the compacted array covers the whole mesh: usable when every uploaded triangle is traced
+        if (u.num_triangles == ctx->num_triangles && u.num_triangles > 0 && ctx->accel_mode != PT_ACCEL_CULL && !ctx->keep_unreachable) {
+            p->tris = ctx->d_tris_live;
+            p->live_count = ctx->d_live_count;
+        }
         p->vnormals = ctx->d_vnormals;
         p->gnormals = ctx->d_gnormals;
         PT_REQUIRE(ctx->accel_mode != PT_ACCEL_BVH || ctx->bvh_built, PT_ERR_STATE, "PT_ACCEL_BVH but no BVH: call pt_build_accel first");
@@ -280,6 +291,8 @@ PtStatus fill_params(PtContext* ctx, PtKernelParams* p, const Program** prog_out
             p->bvh_ids = ctx->bvh.sorted_ids;
         } else if (ctx->accel_mode == PT_ACCEL_CULL) {
             p->cull = ctx->d_cull;
+            p->tris = ctx->d_tris;
+            p->live_count = nullptr;
         }
     } else {
         PT_REQUIRE(ctx->have_spheres, PT_ERR_STATE, "no spheres uploaded: call pt_upload_spheres first");
@@ -344,6 +357,7 @@ PtStatus pt_create(int32_t device, PtContext** out_ctx) {
     if (sched && sched[0] == '0') ctx->sched_mode = 0;
     else if (sched && sched[0] == 't') ctx->sched_mode = 1;
     ctx->wave_slots = prop.multiProcessorCount * 4 * 8;
+    if (const char* k = getenv("PT_KEEP_UNREACHABLE")) ctx->keep_unreachable = k[0] == '1';
     if (const char* f = getenv("PT_SPLIT_FACTOR")) ctx->split_factor = (float)atof(f);  // for experiments
     *out_ctx = ctx;
     return PT_OK;
@@ -449,6 +463,8 @@ PtStatus pt_upload_mesh(PtContext* ctx, const float* vertices, int32_t num_verti
     PT_HIP_TRY(hipMalloc(&ctx->d_indices, nt * 3 * sizeof(uint32_t)));
     PT_HIP_TRY(hipMalloc(&ctx->d_tris, (nt + PT_TRI_PAD) * PT_TRI_FLOATS * sizeof(float)));
     PT_HIP_TRY(hipMemsetAsync(ctx->d_tris + nt * PT_TRI_FLOATS, 0, PT_TRI_PAD * PT_TRI_FLOATS * sizeof(float), ctx->stream));
+    PT_HIP_TRY(hipMalloc(&ctx->d_tris_live, (nt + PT_TRI_PAD) * PT_TRI_FLOATS * sizeof(float)));
+    PT_HIP_TRY(hipMalloc(&ctx->d_live_count, sizeof(uint32_t)));
     PT_HIP_TRY(hipMalloc(&ctx->d_vnormals, nt * 9 * sizeof(float)));
     PT_HIP_TRY(hipMalloc(&ctx->d_gnormals, nt * 3 * sizeof(float)));
     PT_HIP_TRY(hipMalloc(&ctx->d_cull, nt * PT_CULL_FLOATS * sizeof(float)));

@@ -114,6 +114,7 @@ struct PtKernelParams {
     const float* vnormals;              // num_triangles x 9: the three vertex normals (na, nb, nc)
     const float* gnormals;              // num_triangles x 3: normalize(cross(e1, e2))
     const float* cull;                  // num_triangles x PT_CULL_FLOATS, or null = no wave-level culling
+    const uint32_t* live_count;         // device scalar: records in `tris` when it is the compacted array; null = num_triangles
     const float* tris_abs;              // num_triangles x PT_TRI_FLOATS: a, e1, e2 (for rays with their own origin)
     const float* materials;             // num_materials x (r, g, b, e)
     const int32_t* material_ids;        // per triangle
@@ -142,6 +143,8 @@ struct PtKernelParams {
 hipError_t pt_launch_prepare_triangles(const float* vertices, const uint32_t* indices, int32_t num_triangles,
                                        const float ro[3], float* tris, float* vnormals, float* gnormals, float* cull,
                                        float* tris_abs, hipStream_t stream);
+// live <- the records of `tris` that any camera ray can hit at all (e2r > 0), order kept, zero padding after; *live_count <- how many
+hipError_t pt_launch_compact_triangles(const float* tris, int32_t num_triangles, float* live, uint32_t* live_count, hipStream_t stream);
 hipError_t pt_launch_fill_rgba(float* img, size_t num_pixels, float r, float g, float b, float a, hipStream_t stream);
 hipError_t pt_launch_render(const PtKernelParams& p, int program_kind, hipStream_t stream);
 hipError_t pt_launch_present(const float* img, size_t num_pixels, uint32_t* out_rgba8, hipStream_t stream);

@@ -219,21 +219,29 @@ __device__ __forceinline__ Hit intersect_mesh(const float* __restrict__ tris, in
     Hit h;
     h.t = 1.0e38f; h.id = -1; h.u = 0.f; h.v = 0.f; h.ood = 0.f;
     const float4* __restrict__ recs = reinterpret_cast<const float4*>(tris);
+    // the triangle's index travels in the record's last word: the array may be the compacted one (see
+    // pt_compact_triangles_kernel), which keeps the ascending order the strict '<' relies on
+    auto id_of = [](const TriRec& t) { return (int)__float_as_uint(t.d.w); };
 #ifdef PT_V_SIMPLE
-    for (int i = 0; i < n; ++i) test_triangle<false>(load_rec(recs, i), i, rd, h);
+    for (int i = 0; i < n; ++i) { const TriRec t = load_rec(recs, i); test_triangle<false>(t, id_of(t), rd, h); }
 #else
     TriRec a0 = load_rec(recs, 0), a1 = load_rec(recs, 1);
     for (int i = 0; i < n; i += 4) {
         const TriRec b0 = load_rec(recs, i + 2), b1 = load_rec(recs, i + 3);
-        test_triangle<false>(a0, i, rd, h);
-        test_triangle<false>(a1, i + 1, rd, h);
+        test_triangle<false>(a0, id_of(a0), rd, h);
+        test_triangle<false>(a1, id_of(a1), rd, h);
         a0 = load_rec(recs, i + 4);
         a1 = load_rec(recs, i + 5);
-        test_triangle<false>(b0, i + 2, rd, h);
-        test_triangle<false>(b1, i + 3, rd, h);
+        test_triangle<false>(b0, id_of(b0), rd, h);
+        test_triangle<false>(b1, id_of(b1), rd, h);
     }
 #endif
     return h;
+}
+
+// how many records the all-triangles loop visits: all of them, or the count the compaction left on the device
+__device__ __forceinline__ int live_triangles(const PtKernelParams& p) {
+    return p.live_count ? (int)*(const kuint32*)p.live_count : p.num_triangles;
 }
 
 // fs:125-174 for rays with their own origins: same double-buffered scalar record stream.
@@ -624,7 +632,7 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
         Hit h;
         v3 N = V(0.f, 0.f, 0.f);
         if (KIND == 0) h = intersect_world(p.spheres, ro, rd, N);
-        else if (KIND == 1) h = MATERIALS ? intersect_mesh_from(p.tris_abs, p.num_triangles, ro, rd) : intersect_mesh(p.tris, p.num_triangles, rd);
+        else if (KIND == 1) h = MATERIALS ? intersect_mesh_from(p.tris_abs, p.num_triangles, ro, rd) : intersect_mesh(p.tris, live_triangles(p), rd);
         else if (KIND == 2) h = intersect_bvh<MATERIALS>(p, ro, rd, s_stack[threadIdx.x >> 6], node_visits, tri_tests);
         else h = intersect_mesh_culled(p, rd, active, cull0, tri_tests);
         ++trips;
@@ -703,7 +711,7 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_primary_kernel(const PtKer
     Hit h;
     v3 N;
     if (KIND == 0) h = intersect_world(p.spheres, ro, rd, N);
-    else if (KIND == 1) h = intersect_mesh(p.tris, p.num_triangles, rd);
+    else if (KIND == 1) h = intersect_mesh(p.tris, live_triangles(p), rd);
     unsigned nv = 0, tt = 0;
     if (KIND == 2) h = intersect_bvh<false>(p, ro, rd, s_stack[threadIdx.x >> 6], nv, tt);
     if (KIND == 3) h = intersect_mesh_culled(p, rd, in_window, load_cull(reinterpret_cast<const float4*>(p.cull), threadIdx.x & 63, p.num_triangles), tt);
@@ -734,7 +742,7 @@ __global__ __launch_bounds__(256) void pt_prepare_triangles_kernel(const float* 
     t[6] = ap.x; t[7] = ap.y; t[8] = ap.z;
     t[9] = r.x; t[10] = r.y; t[11] = r.z;
     t[12] = dot3(e2, r);
-    t[13] = 0.f; t[14] = 0.f; t[15] = 0.f;
+    t[13] = 0.f; t[14] = 0.f; t[15] = __uint_as_float((uint32_t)i);
     // origin-independent record for rays with their own origins: a, e1, e2
     float* ta = tris_abs + (size_t)i * PT_TRI_FLOATS;
     ta[0] = a.x; ta[1] = a.y; ta[2] = a.z;
@@ -776,6 +784,39 @@ __global__ __launch_bounds__(256) void pt_prepare_triangles_kernel(const float* 
     cr[0] = nab.x; cr[1] = nab.y; cr[2] = nab.z; cr[3] = nbc.x;
     cr[4] = nbc.y; cr[5] = nbc.z; cr[6] = nca.x; cr[7] = nca.y;
     cr[8] = nca.z; cr[9] = front.x; cr[10] = front.y; cr[11] = front.z;
+}
+
+// Every ray starts at the camera (the shader never moves `ro`), so a hit's distance is e2r / det with e2r =
+// dot(e2, cross(ro - a, e1)) fixed per triangle; det >= 1e-4 is positive, so a triangle with e2r <= 0 (the camera is
+// behind its plane, or in it) yields t <= 0 for every ray and fails the shader's `temp > 0.0` (fs:156) always. Such
+// triangles are left out of the array the all-triangles loop walks: same results, fewer tests (closed meshes lose about
+// half their triangles). One workgroup; each thread compacts a contiguous run, so the ascending order is kept.
+__global__ __launch_bounds__(1024) void pt_compact_triangles_kernel(const float4* __restrict__ tris, int n, float4* __restrict__ live,
+                                                                   uint32_t* __restrict__ live_count) {
+    __shared__ uint32_t offset[1024];
+    const int per = (n + 1023) / 1024, begin = min(n, (int)threadIdx.x * per), end = min(n, begin + per);
+    uint32_t mine = 0;
+    for (int i = begin; i < end; ++i) mine += tris[4 * (size_t)i + 3].x > 0.0f ? 1u : 0u;
+    offset[threadIdx.x] = mine;
+    __syncthreads();
+    for (int step = 1; step < 1024; step <<= 1) {  // inclusive scan
+        const uint32_t add = threadIdx.x >= (unsigned)step ? offset[threadIdx.x - step] : 0u;
+        __syncthreads();
+        offset[threadIdx.x] += add;
+        __syncthreads();
+    }
+    const uint32_t total = offset[1023];
+    uint32_t out = offset[threadIdx.x] - mine;
+    for (int i = begin; i < end; ++i) {
+        if (tris[4 * (size_t)i + 3].x > 0.0f) {
+            for (int q = 0; q < 4; ++q) live[4 * (size_t)out + q] = tris[4 * (size_t)i + q];
+            ++out;
+        }
+    }
+    // the loop reads up to PT_TRI_PAD records past the end: all-zero ones (det = 0 fails the cull)
+    if (threadIdx.x < PT_TRI_PAD)
+        for (int q = 0; q < 4; ++q) live[4 * ((size_t)total + threadIdx.x) + q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (threadIdx.x == 0) *live_count = total;
 }
 
 // Present pass: the reference's copy.fs (pow(rgb, 0.454545), copy.fs:18) followed by the float -> 8-bit conversion
@@ -915,6 +956,13 @@ hipError_t pt_launch_prepare_triangles(const float* vertices, const uint32_t* in
     if (num_triangles <= 0) return hipSuccess;
     hipLaunchKernelGGL(pt_prepare_triangles_kernel, dim3((num_triangles + 255) / 256), dim3(256), 0, stream, vertices,
                        indices, num_triangles, ro[0], ro[1], ro[2], tris, vnormals, gnormals, cull, tris_abs);
+    return hipGetLastError();
+}
+
+hipError_t pt_launch_compact_triangles(const float* tris, int32_t num_triangles, float* live, uint32_t* live_count, hipStream_t stream) {
+    if (num_triangles <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pt_compact_triangles_kernel, dim3(1), dim3(1024), 0, stream, reinterpret_cast<const float4*>(tris), num_triangles,
+                       reinterpret_cast<float4*>(live), live_count);
     return hipGetLastError();
 }
 
