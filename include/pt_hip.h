@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 1
+#define PT_ABI_VERSION 2
 
 typedef enum PtStatus {
     PT_OK = 0,
@@ -98,6 +98,8 @@ typedef struct PtUniforms {
 typedef struct PtStats {
     uint64_t rays;             /* closest-hit queries since the last pt_reset_stats(): one per bounce-loop iteration
                                   (the reference's definition, PathTracer.cpp:947; its GLSL mode never counts, :1315) */
+    uint64_t rays_traced;      /* of those, the queries actually evaluated: with primary reuse (pt_set_primary_reuse) the
+                                  camera ray of a pixel is evaluated once per dispatch, not once per sample */
     uint64_t samples;          /* pixel-samples (shader invocations) */
     uint64_t lane_slots;       /* 64 x the loop trips of every wave: rays / lane_slots is the fraction of SIMD lanes
                                   that did useful work (paths in one wave end at different times) */
@@ -156,6 +158,12 @@ PtStatus pt_set_normal_mode(PtContext* ctx, PtNormalMode mode);
  * PT_SHADE_MATERIALS only. A new pt_upload_mesh discards the ids. */
 PtStatus pt_upload_material_ids(PtContext* ctx, const int32_t* ids, int32_t count);
 PtStatus pt_set_shading_mode(PtContext* ctx, PtShadingMode mode);
+/* The shader has no pixel jitter (pathtracing.fs:381-383: the camera ray depends on gl_FragCoord only), so the first
+ * closest-hit query of every sample of a pixel has the same answer. enable != 0 (the default) evaluates it once per
+ * dispatch and pixel and starts every sample of that dispatch from it; 0 evaluates it for every sample like the shader
+ * does. The image is identical either way; PtStats::rays counts the query for every sample in both cases,
+ * PtStats::rays_traced only the evaluations. No effect on dispatches of a single sample. */
+PtStatus pt_set_primary_reuse(PtContext* ctx, int32_t enable);
 /* Builds a linear BVH over the uploaded mesh on the device (Morton codes, radix sort, Karras hierarchy, bottom-up
  * boxes). No counterpart in the reference, whose shader tests every triangle for every ray; needed for scenes beyond a
  * few thousand triangles. A new pt_upload_mesh discards it. Meshes of at most 4 triangles need none (PT_OK, no-op). */

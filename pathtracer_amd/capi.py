@@ -27,7 +27,7 @@ class PtUniforms(C.Structure):
 
 
 class PtStats(C.Structure):
-    _fields_ = [("rays", C.c_uint64), ("samples", C.c_uint64), ("lane_slots", C.c_uint64), ("bvh_node_fetches", C.c_uint64),
+    _fields_ = [("rays", C.c_uint64), ("rays_traced", C.c_uint64), ("samples", C.c_uint64), ("lane_slots", C.c_uint64), ("bvh_node_fetches", C.c_uint64),
                 ("bvh_triangle_fetches", C.c_uint64), ("dispatches", C.c_uint32),
                 ("last_dispatch_ms", C.c_float), ("total_dispatch_ms", C.c_double)]
 
@@ -55,6 +55,7 @@ SIGNATURES = {
     "pt_set_normal_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "pt_upload_material_ids": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "pt_set_shading_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "pt_set_primary_reuse": (C.c_int, [C.c_void_p, C.c_int32]),
     "pt_build_accel": (C.c_int, [C.c_void_p]),
     "pt_set_accel_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "pt_target_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
@@ -172,6 +173,9 @@ class Tracer:
         a = np.ascontiguousarray(ids, np.int32).reshape(-1)
         check(self._lib.pt_upload_material_ids(self._ctx, a.ctypes.data, len(a)), self._lib)
 
+    def set_primary_reuse(self, enable):
+        check(self._lib.pt_set_primary_reuse(self._ctx, 1 if enable else 0), self._lib)
+
     def set_shading_mode(self, mode):
         check(self._lib.pt_set_shading_mode(self._ctx, mode), self._lib)
 
@@ -239,7 +243,7 @@ class Tracer:
     def stats(self):
         s = PtStats()
         check(self._lib.pt_get_stats(self._ctx, C.byref(s)), self._lib)
-        return {"rays": s.rays, "samples": s.samples, "lane_slots": s.lane_slots, "bvh_node_fetches": s.bvh_node_fetches,
+        return {"rays": s.rays, "rays_traced": s.rays_traced, "samples": s.samples, "lane_slots": s.lane_slots, "bvh_node_fetches": s.bvh_node_fetches,
                 "bvh_triangle_fetches": s.bvh_triangle_fetches, "dispatches": s.dispatches,
                 "last_dispatch_ms": s.last_dispatch_ms, "total_dispatch_ms": s.total_dispatch_ms}
 

@@ -98,6 +98,7 @@ struct PtContext {
     size_t sample_scratch_bytes = 0;
     int32_t wave_slots = 0;               // waves the device holds at once (CUs x 4 SIMDs x 8)
     float split_factor = -1.f;            // < 0: chosen per kernel family, see pt_dispatch
+    bool primary_reuse = true;
     bool keep_unreachable = false;        // PT_KEEP_UNREACHABLE=1: the loop walks all records (to measure the compaction)
     int32_t sched_win[4] = {-1, -1, -1, -1};  // window the costs were measured for
     bool sched_have_cost = false;
@@ -243,6 +244,7 @@ PtStatus fill_params(PtContext* ctx, PtKernelParams* p, const Program** prog_out
     p->accum_mode = (int32_t)ctx->accum_mode;
     p->normal_mode = (int32_t)ctx->normal_mode;
     p->counters = ctx->d_counters;
+    p->primary_reuse = ctx->primary_reuse ? 1 : 0;
     if (prog->kind == PT_PROGRAM_MESH) {
         PT_REQUIRE(u.num_triangles >= 0 && u.num_triangles <= ctx->num_triangles, PT_ERR_INVALID_ARGUMENT,
                    "u_NumTriangles = %d but %d triangles are uploaded", u.num_triangles, ctx->num_triangles);
@@ -506,6 +508,12 @@ PtStatus pt_upload_material_ids(PtContext* ctx, const int32_t* ids, int32_t coun
     PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->num_material_ids = count;
     ctx->max_material_id = top;
+    return PT_OK;
+}
+
+PtStatus pt_set_primary_reuse(PtContext* ctx, int32_t enable) {
+    PT_REQUIRE(ctx != nullptr, PT_ERR_INVALID_ARGUMENT, "null context");
+    ctx->primary_reuse = enable != 0;
     return PT_OK;
 }
 
@@ -842,10 +850,11 @@ PtStatus pt_get_stats(PtContext* ctx, PtStats* out) {
     std::vector<unsigned long long> slots((size_t)PT_COUNTER_SLOTS * PT_COUNTER_STRIDE);
     PT_HIP_TRY(hipMemcpyAsync(slots.data(), ctx->d_counters, kCounterBytes, hipMemcpyDeviceToHost, ctx->stream));
     PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    unsigned long long c[4] = {0, 0, 0, 0};
+    unsigned long long c[5] = {0, 0, 0, 0, 0};
     for (size_t k = 0; k < PT_COUNTER_SLOTS; ++k)
-        for (int j = 0; j < 4; ++j) c[j] += slots[k * PT_COUNTER_STRIDE + j];
+        for (int j = 0; j < 5; ++j) c[j] += slots[k * PT_COUNTER_STRIDE + j];
     out->rays = c[0];
+    out->rays_traced = c[4];
     out->samples = ctx->samples;
     out->lane_slots = c[1];
     out->bvh_node_fetches = c[2];

@@ -119,6 +119,7 @@ struct PtKernelParams {
     const float* materials;             // num_materials x (r, g, b, e)
     const int32_t* material_ids;        // per triangle
     int32_t shading_mode;               // PtShadingMode
+    int32_t primary_reuse;              // 1: evaluate a pixel's camera ray once per block instead of once per sample
     const float* bvh_nodes;             // LBVH traversal records, or null = test every triangle in index order
     const float* bvh_tris;              // triangle records in leaf order
     const int32_t* bvh_ids;             // triangle id of each leaf-order record
@@ -128,7 +129,7 @@ struct PtKernelParams {
     const float* src;                   // RGBA32F image read (previous result)
     float* dst;                         // RGBA32F image written
     unsigned long long* counters;       // PT_COUNTER_SLOTS x PT_COUNTER_STRIDE: per slot [0] rays, [1] lane slots spent (wave loop trips x 64),
-                                        // [2] node records, [3] triangle records fetched by the hierarchy walk
+                                        // [2] node records, [3] triangle records fetched by the hierarchy walk, [4] queries actually evaluated
     const PtWorkItem* items;            // work list (block -> item), or null = block b renders tile b with all samples
     const uint32_t* sched_counts;       // [0] number of items, [1] number of split tiles (device scalars written by the scheduler)
     const uint32_t* split_tiles;        // scratch slot -> tile

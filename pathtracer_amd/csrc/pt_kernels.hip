@@ -610,48 +610,91 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
 
     int remaining = in_window ? sample_count : 0;
     int sample = p.first_sample + sample_begin * p.sample_stride;
-    unsigned rays = 0;
-    unsigned trips = 0;  // loop trips of this wave: trips x 64 lane slots were spent for `rays` useful ones
+    unsigned rays = 0;    // closest-hit queries in the reference's sense: one per bounce-loop iteration (PathTracer.cpp:947)
+    unsigned traced = 0;  // queries this lane actually evaluated
+    unsigned trips = 0;   // queries evaluated by the WAVE: trips x 64 lane slots were spent for `traced` useful ones
     unsigned node_visits = 0, tri_tests = 0;  // per WAVE (the BVH walk is wave-uniform): records fetched
 
-    // path state
+    CullRec cull0;
+    if (KIND == 3) cull0 = load_cull(reinterpret_cast<const float4*>(p.cull), threadIdx.x & 63, p.num_triangles);
+
+    auto intersect = [&](v3 o, v3 d, bool want, v3& n_out, float& t_out, int& id_out) -> bool {
+        // wave-wide for KIND 3 (its cull step needs every lane), otherwise only the lanes that want a hit take part
+        Hit h;
+        h.id = -1; h.t = 1.0e38f; h.u = h.v = h.ood = 0.f;
+        v3 n = V(0.f, 0.f, 0.f);
+        if (KIND == 3) {
+            h = intersect_mesh_culled(p, d, want, cull0, tri_tests);
+        } else if (want) {
+            if (KIND == 0) h = intersect_world(p.spheres, o, d, n);
+            else if (KIND == 1) h = MATERIALS ? intersect_mesh_from(p.tris_abs, p.num_triangles, o, d) : intersect_mesh(p.tris, live_triangles(p), d);
+            else h = intersect_bvh<MATERIALS>(p, o, d, s_stack[threadIdx.x >> 6], node_visits, tri_tests);
+        }
+        const bool hit = want && h.id >= 0;
+        if (hit && KIND != 0) n = mesh_normal(p, h);
+        n_out = n; t_out = h.t; id_out = h.id;
+        return hit;
+    };
+
+    // The shader has no pixel jitter: the camera ray of a pixel (fs:381-383) is the same for every sample, and so is what
+    // it hits. With primary reuse the first closest-hit query of a sample is evaluated once per block and pixel and its
+    // result (normal, distance, triangle) is what every further sample of the block starts from.
+    const bool reuse = p.primary_reuse != 0;
+    v3 N0 = V(0.f, 0.f, 0.f);
+    float t0 = 1.0e38f;
+    int id0 = -1;
+    bool hit0 = false;
+    if (reuse) {
+        const bool want0 = remaining > 0;
+        if (KIND == 3 || want0) hit0 = intersect(ro0, rd0, want0, N0, t0, id0);
+        if (__builtin_amdgcn_ballot_w64(want0)) ++trips;
+        if (want0) { ++traced; ++rays; }  // ++rays: the first sample's camera-ray query; later samples count theirs when they start
+    }
+
+    // path state of the sample in flight
     v3 ro = ro0, rd = rd0;
     v3 energy = V(1.0f, 1.0f, 1.0f);      // the reference mode keeps the three channels equal and only uses .x
     v3 emitted = V(0.f, 0.f, 0.f);
     int level = 0;
     rng.samples = (float)sample;
     rng.sx = 0.0f;
+    // the hit waiting to be shaded: the reused primary hit at the start of a sample, later the one found by the last query
+    bool pending = reuse;           // false: the sample's first query is still to be evaluated
+    bool pend_hit = hit0;
+    v3 pend_n = N0;
+    float pend_t = t0;
+    int pend_id = id0;
 
-    CullRec cull0;
-    if (KIND == 3) cull0 = load_cull(reinterpret_cast<const float4*>(p.cull), threadIdx.x & 63, p.num_triangles);
-
-    // KIND 3 keeps all 64 lanes in the loop until the wave is done (its cull step is a wave-wide operation); lanes
-    // without a ray left are masked by `active`. The other kinds simply let finished lanes drop out.
+    // One loop trip = [shade the pending hit, Shade() fs:224-361] then [closest hit of the new direction]; a sample that
+    // ends (miss, throughput 0, depth reached: fs:388,402) is folded into the pixel and the lane starts its next sample
+    // in the same trip, so lanes of a wave stay busy although their paths differ in length.
+    // KIND 3 keeps all 64 lanes in the loop until the wave is done (its cull step is a wave-wide operation); the other
+    // kinds simply let finished lanes drop out.
     while (KIND == 3 ? __builtin_amdgcn_ballot_w64(remaining > 0) != 0 : remaining > 0) {
-        const bool active = remaining > 0;
-        Hit h;
-        v3 N = V(0.f, 0.f, 0.f);
-        if (KIND == 0) h = intersect_world(p.spheres, ro, rd, N);
-        else if (KIND == 1) h = MATERIALS ? intersect_mesh_from(p.tris_abs, p.num_triangles, ro, rd) : intersect_mesh(p.tris, live_triangles(p), rd);
-        else if (KIND == 2) h = intersect_bvh<MATERIALS>(p, ro, rd, s_stack[threadIdx.x >> 6], node_visits, tri_tests);
-        else h = intersect_mesh_culled(p, rd, active, cull0, tri_tests);
-        ++trips;
-        if (KIND == 3 && !active) continue;
-        ++rays;
-        const bool hit = h.id >= 0;
-        if (hit) {
-            if (KIND != 0) N = mesh_normal(p, h);
-            if (MATERIALS) {
-                const v3 P = ro + rd * h.t;  // recPoint, fs:163
-                shade_materials(rng, p.materials, p.material_ids[h.id], energy, emitted, ro, rd, P, N);
-            } else {
-                shade(rng, energy.x, rd, N);
+        const bool live = remaining > 0;
+        bool done = false;
+        if (live && pending) {
+            if (pend_hit) {
+                if (MATERIALS) {
+                    const v3 P = ro + rd * pend_t;  // recPoint, fs:163
+                    shade_materials(rng, p.materials, p.material_ids[pend_id], energy, emitted, ro, rd, P, pend_n);
+                } else {
+                    shade(rng, energy.x, rd, pend_n);
+                }
             }
+            ++level;
+            const bool spent = MATERIALS ? (energy.x == 0.0f && energy.y == 0.0f && energy.z == 0.0f) : energy.x == 0.0f;
+            done = !pend_hit || spent || level >= p.depth;
         }
-        ++level;
-        // fs:402 and the loop bound fs:388
-        const bool spent = MATERIALS ? (energy.x == 0.0f && energy.y == 0.0f && energy.z == 0.0f) : energy.x == 0.0f;
-        if (!hit || spent || level >= p.depth) {
+        const bool want = live && !done;
+        if (KIND == 3 || want) pend_hit = intersect(ro, rd, want, pend_n, pend_t, pend_id);
+        if (__builtin_amdgcn_ballot_w64(want)) ++trips;
+        if (want) {
+            ++traced; ++rays;
+            pending = true;
+            done = !pend_hit;  // a miss ends the sample in this same trip
+        }
+        if (live && done) {
             // fs:408-415
             const float t = 0.5f * (rd.y + 1.0f);
             const float omt = 1.0f - t;
@@ -673,18 +716,21 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
             ro = ro0; rd = rd0; energy = V(1.0f, 1.0f, 1.0f); emitted = V(0.f, 0.f, 0.f); level = 0;
             rng.samples = (float)sample;
             rng.sx = 0.0f;
+            pending = reuse; pend_hit = hit0; pend_n = N0; pend_t = t0; pend_id = id0;
+            if (reuse && remaining > 0) ++rays;  // the new sample's camera-ray query, answered by the reused result
         }
     }
     if (in_window && scratch_slot < 0) {
         const float alpha = p.accum_mode == 0 ? 1.0f : prev.w + (float)p.num_samples;
         reinterpret_cast<float4*>(p.dst)[pix] = make_float4(mr, mg, mb, alpha);
     }
-    const unsigned long long wave_rays = wave_sum(rays);
+    const unsigned long long wave_rays = wave_sum(rays), wave_traced = wave_sum(traced);
     const unsigned wave_trips = __builtin_amdgcn_readfirstlane(__reduce_max_trips(trips));
     if ((threadIdx.x & 63) == 0 && wave_rays) {
         unsigned long long* counters = p.counters + (size_t)(blockIdx.x % PT_COUNTER_SLOTS) * PT_COUNTER_STRIDE;
         atomicAdd(&counters[0], wave_rays);
         atomicAdd(&counters[1], (unsigned long long)wave_trips * 64ull);
+        atomicAdd(&counters[4], wave_traced);
         // Scheduling cost of this tile: proportional to the time the wave took. A trip of the all-triangles loop always
         // costs the same; a trip through the hierarchy costs its node and triangle records plus a fixed share.
         if (p.tile_cost) {

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--lib", default=None)
     ap.add_argument("--accel", default="auto", choices=["auto", "brute", "bvh", "cull"])
     ap.add_argument("--shading", default="reference", choices=["reference", "materials"])
+    ap.add_argument("--no-reuse", action="store_true", help="evaluate the camera ray for every sample, like the shader")
     args = ap.parse_args()
     from pathtracer_amd import Tracer
     from pathtracer_amd.scenes import SceneData
@@ -36,6 +37,7 @@ def main():
     else:
         build_s = 0.0
         t.set_accel_mode({"brute": 1, "cull": 3, "auto": 0}[args.accel])
+    t.set_primary_reuse(not args.no_reuse)
     t.enable_timing(True)
     t.dispatch(1, 1, 1)
     t.finish()
@@ -49,8 +51,9 @@ def main():
     st = t.stats()
     ms = st["total_dispatch_ms"] / st["dispatches"]
     print(json.dumps({"workload": args.workload, "size": [scene.width, scene.height], "spp": args.spp, "triangles": scene.num_triangles,
-                      "accel": args.accel, "shading": args.shading, "bvh_build_s": round(build_s, 4), "kernel_ms": ms, "per_rep_ms": per_rep, "Grays_per_s": st["rays"] / st["dispatches"] / ms * 1e-6,
-                      "rays_per_sample": st["rays"] / st["samples"], "lane_utilisation": st["rays"] / st["lane_slots"],
+                      "accel": args.accel, "shading": args.shading, "bvh_build_s": round(build_s, 4), "kernel_ms": ms, "per_rep_ms": per_rep, "Grays_per_s": st["rays"] / st["dispatches"] / ms * 1e-6, "traced_Grays_per_s": st["rays_traced"] / st["dispatches"] / ms * 1e-6,
+                      "Gsamples_per_s": st["samples"] / st["dispatches"] / ms * 1e-6, "primary_reuse": not args.no_reuse,
+                      "rays_per_sample": st["rays"] / st["samples"], "lane_utilisation": st["rays_traced"] / max(1, st["lane_slots"]),
                       "triangle_records_per_wave_ray": st["bvh_triangle_fetches"] * 64 / st["lane_slots"],
                       "node_records_per_wave_ray": st["bvh_node_fetches"] * 64 / st["lane_slots"]}))
     t.close()
