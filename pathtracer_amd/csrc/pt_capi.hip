@@ -735,6 +735,13 @@ PtStatus pt_dispatch(PtContext* ctx, int32_t first_sample, int32_t num_samples, 
                 ctx->list_samples = num_samples;
                 ctx->list_max_split = max_split;
                 ctx->list_age = 0;
+                if (getenv("PT_DEBUG_SCHED")) {  // what the scheduler decided (diagnostics; synchronises)
+                    uint32_t c[2] = {0, 0};
+                    (void)hipMemcpyAsync(c, ctx->d_sched_counts, sizeof c, hipMemcpyDeviceToHost, ctx->stream);
+                    (void)hipStreamSynchronize(ctx->stream);
+                    fprintf(stderr, "[pt sched] %d tiles, %d samples, costs from %lld samples: %u items, %u split tiles (limit %d)\n", tiles,
+                            num_samples, (long long)ctx->cost_samples, c[0], c[1], max_split);
+                }
                 ctx->list_basis = ctx->cost_samples > 0 ? ctx->cost_samples : 1;
                 ctx->cost_samples = 0;
             }

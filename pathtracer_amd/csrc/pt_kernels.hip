@@ -12,6 +12,8 @@
 // over triangles fetches each 64-byte record with scalar loads and every lane tests its own ray against it.
 #include "pt_internal.h"
 
+#include <cstdlib>
+
 namespace {
 
 struct v3 { float x, y, z; };
@@ -639,7 +641,7 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
     // The shader has no pixel jitter: the camera ray of a pixel (fs:381-383) is the same for every sample, and so is what
     // it hits. With primary reuse the first closest-hit query of a sample is evaluated once per block and pixel and its
     // result (normal, distance, triangle) is what every further sample of the block starts from.
-    const bool reuse = p.primary_reuse != 0;
+    const bool reuse = p.primary_reuse != 0 && p.depth > 0;  // u_Depth <= 0: the bounce loop (fs:388) never runs, no query at all
     v3 N0 = V(0.f, 0.f, 0.f);
     float t0 = 1.0e38f;
     int id0 = -1;
@@ -673,7 +675,9 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
     while (KIND == 3 ? __builtin_amdgcn_ballot_w64(remaining > 0) != 0 : remaining > 0) {
         const bool live = remaining > 0;
         bool done = false;
-        if (live && pending) {
+        if (live && p.depth <= 0) {
+            done = true;
+        } else if (live && pending) {
             if (pend_hit) {
                 if (MATERIALS) {
                     const v3 P = ro + rd * pend_t;  // recPoint, fs:163
@@ -931,7 +935,7 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_fold_samples_kernel(const 
 // are handed out atomically, so the list is always a complete cover). Also clears the costs for the next accumulation.
 __global__ __launch_bounds__(1024) void pt_schedule_items_kernel(uint32_t* __restrict__ cost, PtWorkItem* __restrict__ items,
                                                                  uint32_t* __restrict__ counts, uint32_t* __restrict__ split_tiles, int n,
-                                                                 int num_samples, int max_split) {
+                                                                 int num_samples, int max_split, int sort) {
     __shared__ uint32_t hist[64], start[64];
     __shared__ unsigned long long total;
     __shared__ uint32_t num_split;
@@ -943,7 +947,8 @@ __global__ __launch_bounds__(1024) void pt_schedule_items_kernel(uint32_t* __res
     atomicAdd(&total, mine);
     __syncthreads();
     const unsigned long long granule = max_split > 0 ? total / (unsigned long long)max_split + 1ull : ~0ull;
-    auto bucket = [](uint32_t c) -> int {
+    auto bucket = [sort](uint32_t c) -> int {
+        if (!sort) return 0;
         if (c < 2) return (int)c;
         const int lg = 31 - __builtin_clz(c);
         const int half = (int)((c >> (lg - 1)) & 1u);
@@ -1031,8 +1036,9 @@ hipError_t pt_launch_present(const float* img, size_t num_pixels, uint32_t* out_
 hipError_t pt_launch_schedule_items(uint32_t* tile_cost, PtWorkItem* items, uint32_t* sched_counts, uint32_t* split_tiles, int num_tiles,
                                     int num_samples, int max_split_tiles, hipStream_t stream) {
     if (num_tiles <= 0) return hipSuccess;
+    static const int sort = getenv("PT_SCHED_SORT") ? atoi(getenv("PT_SCHED_SORT")) : 1;
     hipLaunchKernelGGL(pt_schedule_items_kernel, dim3(1), dim3(1024), 0, stream, tile_cost, items, sched_counts, split_tiles, num_tiles,
-                       num_samples, max_split_tiles);
+                       num_samples, max_split_tiles, sort);
     return hipGetLastError();
 }
 

@@ -1,0 +1,205 @@
+"""Edge cases of the HIP path against the CPU oracle (bit for bit): tiny and ragged images, windows that cut tiles, bounce
+limits 0 and 1, no triangles traced, degenerate and duplicated triangles, long sample ranges with strides, argument errors."""
+import numpy as np
+import pytest
+
+import pt_oracle as po
+from helpers import load_case, n_bit_mismatch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tracer():
+    from pathtracer_amd import Tracer
+    t = Tracer(0)
+    yield t
+    t.close()
+
+
+def upload(t, fx, W, H, depth=10, ntri=None, cam=None, kind=1):
+    prog = t.program_create(kind)
+    t.use_program(prog)
+    t.upload_spheres(fx["spheres"])
+    t.upload_materials(fx["materials"])
+    t.upload_mesh(fx["vertices"], fx["indices"])
+    t.set_normal_mode(int(fx["normal_mode"]))
+    t.set_shading_mode(0)
+    t.set_accel_mode(0)
+    t.set_accum_mode(0)
+    t.target_create(W, H)
+    cam = po.camera(60.0, W, H, (0, 0, 0), (0, 0, 1), (0, 1, 0)) if cam is None else cam
+    n = len(fx["indices"]) if ntri is None else ntri
+    t.set_uniforms(cam, n, depth)
+    scene = po.Scene(fx["vertices"], fx["indices"], fx["spheres"], fx["materials"])
+    u = po.uniforms(cam, W, H, n, depth, kind, int(fx["normal_mode"]))
+    return prog, scene, u
+
+
+@pytest.mark.parametrize("size", [(1, 1), (7, 3), (9, 17), (64, 1), (1, 70), (130, 66)])
+@pytest.mark.parametrize("kind", [0, 1])
+def test_small_and_ragged_images(tracer, size, kind):
+    fx = load_case("monkey_mesh_128")
+    W, H = size
+    prog, scene, u = upload(tracer, fx, W, H, kind=kind)
+    ids, ts = tracer.readback_primary()
+    tracer.dispatch(1, 5, 1)
+    tracer.finish()
+    oids, ots, _ = po.primary(scene, u)
+    ref, rays = po.render(scene, u, 1, 5)
+    assert np.array_equal(ids, oids) and n_bit_mismatch(ts, ots) == 0
+    assert n_bit_mismatch(tracer.readback(), ref) == 0
+    assert tracer.stats()["rays"] >= W * H * 5
+    tracer.reset_stats()
+    tracer.program_destroy(prog)
+
+
+@pytest.mark.parametrize("accel", [1, 2])
+@pytest.mark.parametrize("window", [(3, 5, 1, 1), (5, 9, 11, 7), (0, 0, 128, 1), (127, 0, 1, 128), (17, 33, 90, 41)])
+def test_windows_that_cut_tiles(tracer, window, accel):
+    """Only the window is rendered; what lies outside keeps the clear value. Twice, so that the second dispatch runs from a
+    work list with split tiles."""
+    fx = load_case("monkey_mesh_128")
+    prog, scene, u = upload(tracer, fx, 128, 128)
+    tracer.build_accel()
+    tracer.set_accel_mode(accel)
+    x0, y0, w, h = window
+    tracer.set_window(*window)
+    ref, _ = po.render(scene, u, 1, 6, window=window)
+    for _ in range(2):
+        tracer.target_clear()
+        tracer.dispatch(1, 6, 1)
+        tracer.finish()
+        img = tracer.readback()
+        assert n_bit_mismatch(img, ref) == 0
+    outside = np.ones((128, 128), bool)
+    outside[y0:y0 + h, x0:x0 + w] = False
+    assert np.all(img[outside][:, :3] == 0.0) and np.all(img[..., 3] == 1.0)
+    tracer.set_window()
+    tracer.set_accel_mode(0)
+    tracer.program_destroy(prog)
+
+
+@pytest.mark.parametrize("depth", [0, 1, 2, 3])
+@pytest.mark.parametrize("reuse", [True, False])
+def test_bounce_limits(tracer, depth, reuse):
+    """u_Depth bounds the bounce loop (fs:388): 0 = no closest-hit query at all, the sample is the sky in the camera
+    direction; 1 = the camera ray only."""
+    fx = load_case("cornell_geo_128")
+    prog, scene, u = upload(tracer, fx, 128, 128, depth=depth, cam=fx["camera"])
+    tracer.set_primary_reuse(reuse)
+    tracer.reset_stats()
+    tracer.dispatch(1, 4, 1)
+    tracer.finish()
+    ref, rays = po.render(scene, u, 1, 4, threads=8)
+    assert n_bit_mismatch(tracer.readback(), ref) == 0
+    st = tracer.stats()
+    assert st["rays"] == rays
+    if depth == 0:
+        assert rays == 0 and st["rays_traced"] == 0
+    if depth == 1:
+        assert rays == 128 * 128 * 4 and st["rays_traced"] == (128 * 128 if reuse else rays)
+    tracer.set_primary_reuse(True)
+    tracer.program_destroy(prog)
+
+
+def test_no_triangles_traced(tracer):
+    fx = load_case("monkey_mesh_128")
+    prog, scene, u = upload(tracer, fx, 64, 48, ntri=0)
+    ids, _ = tracer.readback_primary()
+    tracer.dispatch(3, 2, 4)
+    tracer.finish()
+    assert np.all(ids == -1)
+    img = tracer.readback()
+    # every sample is the sky colour of the camera ray: the mean of equal values, folded with weights 1/3 and 1/7
+    sky = np.zeros((48, 64, 4), np.float32)
+    sky[..., 3] = 1.0
+    u1 = po.uniforms(np.asarray(po.camera(60.0, 64, 48, (0, 0, 0), (0, 0, 1), (0, 1, 0))), 64, 48, 0, 10, 1, 0)
+    a, _ = po.render(scene, u1, 3, 1, sky.copy())
+    b, _ = po.render(scene, u1, 7, 1, a)
+    assert n_bit_mismatch(img, b) == 0
+    tracer.program_destroy(prog)
+
+
+@pytest.mark.parametrize("accel", [1, 2])
+def test_degenerate_and_duplicated_triangles(tracer, accel):
+    """Zero-area triangles (collapsed to a point, to a line), exact duplicates (the lower index must win) and triangles
+    seen edge-on, mixed into a random soup."""
+    rng = np.random.default_rng(5)
+    nt = 240
+    base = rng.uniform(-1.5, 1.5, (nt, 1, 3)) + np.array([0, 0, 5.0])
+    tri = (base + rng.uniform(-0.8, 0.8, (nt, 3, 3))).astype(np.float32)
+    tri[10:20, 1] = tri[10:20, 0]; tri[10:20, 2] = tri[10:20, 0]          # points
+    tri[20:30, 2] = (tri[20:30, 0] + tri[20:30, 1]) * np.float32(0.5)     # lines
+    tri[120:180] = tri[30:90]                                              # duplicates of earlier triangles
+    tri[180:190, :, 0] = 0.0                                               # in the plane x = 0 that contains the camera
+    nrm = rng.normal(size=(nt * 3, 3)).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    verts = np.concatenate([tri.reshape(-1, 3), nrm], axis=1).astype(np.float32)
+    idx = np.arange(nt * 3, dtype=np.uint32).reshape(-1, 3)
+    sph, mat = po.reference_spheres_and_materials()
+    fx = {"vertices": verts, "indices": idx, "spheres": sph, "materials": mat, "normal_mode": 0}
+    prog, scene, u = upload(tracer, fx, 96, 80)
+    tracer.build_accel()
+    tracer.set_accel_mode(accel)
+    ids, ts = tracer.readback_primary()
+    tracer.dispatch(1, 4, 1)
+    tracer.finish()
+    oids, ots, _ = po.primary(scene, u, threads=8)
+    ref, rays = po.render(scene, u, 1, 4, threads=8)
+    assert np.array_equal(ids, oids) and n_bit_mismatch(ts, ots) == 0
+    assert not np.isin(ids, np.arange(120, 180)).any(), "a duplicate with the higher index won a tie"
+    assert not np.isin(ids, np.arange(10, 30)).any()
+    assert n_bit_mismatch(tracer.readback(), ref) == 0
+    assert tracer.stats()["rays"] >= 96 * 80 * 4
+    tracer.set_accel_mode(0)
+    tracer.reset_stats()
+    tracer.program_destroy(prog)
+
+
+def test_long_strided_sample_range(tracer):
+    """200 samples with stride 5 from index 3 in one dispatch equal 200 single-sample dispatches with those indices."""
+    fx = load_case("world_128")
+    prog, scene, u = upload(tracer, fx, 40, 24, kind=0)
+    tracer.dispatch(3, 200, 5)
+    tracer.finish()
+    batch = tracer.readback()
+    tracer.target_clear()
+    for k in range(200):
+        tracer.dispatch(3 + 5 * k, 1, 1)
+    tracer.finish()
+    assert n_bit_mismatch(tracer.readback(), batch) == 0
+    rgba = None
+    for k in range(200):
+        rgba, _ = po.render(scene, u, 3 + 5 * k, 1, rgba)
+    assert n_bit_mismatch(batch, rgba) == 0
+    tracer.program_destroy(prog)
+
+
+def test_argument_errors(tracer):
+    from pathtracer_amd import PtError
+    t = tracer
+    fx = load_case("monkey_mesh_128")
+    prog, _, _ = upload(t, fx, 16, 16)
+    for bad in [(0, 1, 1), (1, 0, 1), (1, 1, 0), (1 << 24, 2, 1), (1, 1 << 23, 3)]:
+        with pytest.raises(PtError):
+            t.dispatch(*bad)
+    with pytest.raises(PtError):
+        t.target_create(0, 16)
+    with pytest.raises(PtError):
+        t.target_create(16, 70000)
+    t.target_create(16, 16)
+    with pytest.raises(PtError):
+        t.set_window(8, 8, 16, 4)          # sticks out of the image
+    with pytest.raises(PtError):
+        t.set_uniforms(fx["camera"], len(fx["indices"]) + 1, 10)
+        t.dispatch(1, 1, 1)                # more triangles than uploaded
+    t.set_uniforms(fx["camera"], len(fx["indices"]), 10)
+    with pytest.raises(PtError):
+        t.set_accel_mode(2)
+        t.upload_mesh(fx["vertices"], fx["indices"])   # drops the hierarchy
+        t.dispatch(1, 1, 1)                # PT_ACCEL_BVH without one
+    t.set_accel_mode(0)
+    t.dispatch(1 << 24, 1, 1)              # the last representable sample index is fine
+    t.finish()
+    t.program_destroy(prog)
