@@ -60,6 +60,10 @@ typedef enum PtAccelMode {
                            (128 in PT_SHADE_MATERIALS) */
     PT_ACCEL_BRUTE = 1, /* the shader's own loop over all triangles in index order, pathtracing.fs:129 */
     PT_ACCEL_BVH = 2,   /* require the LBVH: pt_dispatch fails with PT_ERR_STATE when none is built */
+    PT_ACCEL_GRID = 4,  /* require the direction grid (built by pt_build_accel, rebuilt when the camera position changes): the
+                           shader never moves its ray origin, so every query is "what does the camera position see in this
+                           direction"; directions are binned into cube-map cells that list the triangles they can hit.
+                           Reference shading only (PT_SHADE_MATERIALS moves the origin) */
     PT_ACCEL_CULL = 3   /* all-triangles loop that skips, 64 triangles at a time, those no ray of the wave can reach;
                            exact, but measured slower than BRUTE (36 triangles) and BVH (>= 64): kept for experiments */
 } PtAccelMode;
@@ -105,6 +109,8 @@ typedef struct PtStats {
                                   that did useful work (paths in one wave end at different times) */
     uint64_t bvh_node_fetches; /* LBVH traversal: 64-byte node records fetched, counted once per WAVE (the walk is per wave) */
     uint64_t bvh_triangle_fetches; /* LBVH traversal: 64-byte triangle records (+4-byte id) fetched, once per wave */
+    uint64_t grid_triangle_tests; /* direction grid: triangle tests, counted per ray */
+    uint64_t grid_entries;     /* direction grid as currently built: total length of its cell lists (0 = not built) */
     uint32_t dispatches;       /* render-kernel launches */
     float last_dispatch_ms;    /* duration of the most recent render kernel; 0 unless timing is enabled */
     double total_dispatch_ms;  /* sum over dispatches since the last reset; 0 unless timing is enabled */

@@ -44,7 +44,7 @@ def build_hip(force=False, save_temps=False, extra_flags=(), tag=""):
     """tag/extra_flags build an experimental variant next to the product library (tools/ab_bench.py)."""
     os.makedirs(LIB, exist_ok=True)
     out = os.path.join(LIB, f"libpt_hip{('__' + tag) if tag else ''}.so")
-    srcs = [os.path.join(CSRC, f) for f in ("pt_kernels.hip", "pt_bvh.hip", "pt_capi.hip")]
+    srcs = [os.path.join(CSRC, f) for f in ("pt_kernels.hip", "pt_bvh.hip", "pt_grid.hip", "pt_capi.hip")]
     deps = srcs + [os.path.join(CSRC, "pt_internal.h"), os.path.join(ROOT, "include", "pt_hip.h"), __file__]
     if not force and not _newer(out, deps):
         return out

@@ -16,7 +16,7 @@ PT_ERR_INVALID_ARGUMENT, PT_ERR_HIP, PT_ERR_STATE, PT_ERR_NO_DEVICE, PT_ERR_UNSU
 PROGRAM_WORLD, PROGRAM_MESH = 0, 1
 NORMALS_VERTEX, NORMALS_GEOMETRIC = 0, 1
 ACCUM_MEAN, ACCUM_SUM = 0, 1
-ACCEL_AUTO, ACCEL_BRUTE, ACCEL_BVH, ACCEL_CULL = 0, 1, 2, 3
+ACCEL_AUTO, ACCEL_BRUTE, ACCEL_BVH, ACCEL_CULL, ACCEL_GRID = 0, 1, 2, 3, 4
 SHADE_REFERENCE, SHADE_MATERIALS = 0, 1
 
 
@@ -28,7 +28,8 @@ class PtUniforms(C.Structure):
 
 class PtStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("rays_traced", C.c_uint64), ("samples", C.c_uint64), ("lane_slots", C.c_uint64), ("bvh_node_fetches", C.c_uint64),
-                ("bvh_triangle_fetches", C.c_uint64), ("dispatches", C.c_uint32),
+                ("bvh_triangle_fetches", C.c_uint64), ("grid_triangle_tests", C.c_uint64), ("grid_entries", C.c_uint64),
+                ("dispatches", C.c_uint32),
                 ("last_dispatch_ms", C.c_float), ("total_dispatch_ms", C.c_double)]
 
 
@@ -244,7 +245,8 @@ class Tracer:
         s = PtStats()
         check(self._lib.pt_get_stats(self._ctx, C.byref(s)), self._lib)
         return {"rays": s.rays, "rays_traced": s.rays_traced, "samples": s.samples, "lane_slots": s.lane_slots, "bvh_node_fetches": s.bvh_node_fetches,
-                "bvh_triangle_fetches": s.bvh_triangle_fetches, "dispatches": s.dispatches,
+                "bvh_triangle_fetches": s.bvh_triangle_fetches, "grid_triangle_tests": s.grid_triangle_tests,
+                "grid_entries": s.grid_entries, "dispatches": s.dispatches,
                 "last_dispatch_ms": s.last_dispatch_ms, "total_dispatch_ms": s.total_dispatch_ms}
 
     def reset_stats(self):

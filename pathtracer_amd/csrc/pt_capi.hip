@@ -78,6 +78,12 @@ struct PtContext {
     bool bvh_built = false;
     int32_t bvh_refit_passes = 0;
     PtAccelMode accel_mode = PT_ACCEL_AUTO;
+    // direction grid (optional, rebuilt with the records when the camera position changes)
+    PtGridBuild grid{};
+    bool grid_wanted = false;   // pt_build_accel was called for this mesh
+    bool grid_built = false;
+    int32_t grid_res_override = 0;
+    uint64_t grid_entries = 0;
 
     // target
     float* d_image[2] = {nullptr, nullptr};
@@ -99,6 +105,7 @@ struct PtContext {
     int32_t wave_slots = 0;               // waves the device holds at once (CUs x 4 SIMDs x 8)
     float split_factor = -1.f;            // < 0: chosen per kernel family, see pt_dispatch
     bool primary_reuse = true;
+    bool auto_grid = false;               // PT_AUTO_GRID=1: PT_ACCEL_AUTO prefers the direction grid
     bool keep_unreachable = false;        // PT_KEEP_UNREACHABLE=1: the loop walks all records (to measure the compaction)
     int32_t sched_win[4] = {-1, -1, -1, -1};  // window the costs were measured for
     bool sched_have_cost = false;
@@ -188,8 +195,61 @@ void free_bvh(PtContext* ctx) {
     ctx->bvh_built = false;
 }
 
+void free_grid(PtContext* ctx) {
+    PtGridBuild& g = ctx->grid;
+    void* ptrs[] = {g.cell_count, g.cell_start, g.list, g.scan_tmp};
+    for (void* q : ptrs)
+        if (q) (void)hipFree(q);
+    g = PtGridBuild{};
+    ctx->grid_built = false;
+}
+
+// Cube-map resolution per face: about four cells per triangle over the sphere, within [128, 2048]
+int grid_resolution(const PtContext* ctx) {
+    if (ctx->grid_res_override > 0) return ctx->grid_res_override;
+    int res = 128;
+    while (res < 2048 && (double)6 * res * res < 4.0 * (double)ctx->num_triangles) res *= 2;
+    return res;
+}
+
+PtStatus build_grid(PtContext* ctx) {
+    const int res = grid_resolution(ctx);
+    PtGridBuild& g = ctx->grid;
+    const size_t cells = (size_t)6 * res * res;
+    if (g.res != res) {
+        free_grid(ctx);
+        g.res = res;
+        g.scan_tmp_bytes = pt_grid_scan_temp_bytes(cells);
+        PT_HIP_TRY(hipMalloc(&g.cell_count, (cells + 1) * sizeof(uint32_t)));
+        PT_HIP_TRY(hipMalloc(&g.cell_start, (cells + 1) * sizeof(uint32_t)));
+        PT_HIP_TRY(hipMalloc(&g.scan_tmp, g.scan_tmp_bytes ? g.scan_tmp_bytes : 16));
+    }
+    ctx->grid_built = false;
+    PT_HIP_TRY(pt_grid_count(g, ctx->d_tris, ctx->num_triangles, ctx->stream));
+    uint32_t total = 0;
+    PT_HIP_TRY(hipMemcpyAsync(&total, g.cell_start + cells, sizeof total, hipMemcpyDeviceToHost, ctx->stream));
+    PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    // a list that would not fit 2^31 entries (or 8 GiB) means triangles that each cover a large part of a very fine
+    // grid: leave the grid unbuilt, the other search modes still work
+    if ((uint64_t)total >= ((uint64_t)1 << 31)) return PT_OK;
+    if ((size_t)total > g.list_capacity) {
+        if (g.list) (void)hipFree(g.list);
+        g.list = nullptr;
+        g.list_capacity = 0;
+        const size_t cap = (size_t)total + (size_t)total / 8 + 64;
+        PT_HIP_TRY(hipMalloc(&g.list, cap * sizeof(uint32_t)));
+        g.list_capacity = cap;
+    }
+    PT_HIP_TRY(pt_grid_fill(g, ctx->d_tris, ctx->num_triangles, ctx->stream));
+    ctx->grid_entries = total;
+    ctx->grid_built = true;
+    return PT_OK;
+}
+
 void free_mesh(PtContext* ctx) {
     free_bvh(ctx);
+    free_grid(ctx);
+    ctx->grid_wanted = false;
     float** f[] = {&ctx->d_vertices, &ctx->d_tris, &ctx->d_vnormals, &ctx->d_gnormals, &ctx->d_cull, &ctx->d_tris_abs, &ctx->d_tris_live};
     if (ctx->d_live_count) (void)hipFree(ctx->d_live_count);
     ctx->d_live_count = nullptr;
@@ -219,6 +279,10 @@ PtStatus ensure_records(PtContext* ctx) {
         // absolute-box variant: its padding scales with the largest coordinate a ray origin or a box can have
         ctx->bvh.scene_scale = std::max(ctx->mesh_extent, std::max(std::fabs(ro[0]), std::max(std::fabs(ro[1]), std::fabs(ro[2]))));
         PT_HIP_TRY(pt_bvh_emit(ctx->bvh, ro, ctx->d_tris, ctx->d_tris_abs, ctx->stream));
+    }
+    if (ctx->grid_wanted) {
+        PtStatus gs = build_grid(ctx);
+        if (gs != PT_OK) return gs;
     }
     memcpy(ctx->records_ro, ro, sizeof ctx->records_ro);
     ctx->records_valid = true;
@@ -271,7 +335,16 @@ PtStatus fill_params(PtContext* ctx, PtKernelParams* p, const Program** prog_out
         PT_REQUIRE(use_bvh || ctx->accel_mode != PT_ACCEL_BVH, PT_ERR_STATE, "the BVH covers all %d triangles but u_NumTriangles = %d",
                    ctx->num_triangles, u.num_triangles);
         p->shading_mode = (int32_t)ctx->shading_mode;
-        if (ctx->shading_mode == PT_SHADE_MATERIALS) {
+        PT_REQUIRE(ctx->accel_mode != PT_ACCEL_GRID || (ctx->grid_built && ctx->shading_mode == PT_SHADE_REFERENCE && u.num_triangles == ctx->num_triangles),
+                   PT_ERR_STATE, "PT_ACCEL_GRID needs pt_build_accel, PT_SHADE_REFERENCE and u_NumTriangles = all %d triangles", ctx->num_triangles);
+        const bool use_grid = ctx->grid_built && ctx->shading_mode == PT_SHADE_REFERENCE && u.num_triangles == ctx->num_triangles &&
+                              (ctx->accel_mode == PT_ACCEL_GRID || (ctx->accel_mode == PT_ACCEL_AUTO && ctx->auto_grid));
+        if (use_grid) {
+            p->grid_start = ctx->grid.cell_start;
+            p->grid_list = ctx->grid.list;
+            p->grid_tris = ctx->d_tris;
+            p->grid_res = ctx->grid.res;
+        } else if (ctx->shading_mode == PT_SHADE_MATERIALS) {
             PT_REQUIRE(ctx->accel_mode != PT_ACCEL_CULL, PT_ERR_STATE, "PT_ACCEL_CULL serves rays from the camera only; PT_SHADE_MATERIALS moves the origin");
             PT_REQUIRE(ctx->d_materials != nullptr, PT_ERR_STATE, "PT_SHADE_MATERIALS but no material table: call pt_upload_materials first");
             PT_REQUIRE(ctx->num_material_ids == ctx->num_triangles, PT_ERR_STATE,
@@ -359,6 +432,8 @@ PtStatus pt_create(int32_t device, PtContext** out_ctx) {
     if (sched && sched[0] == '0') ctx->sched_mode = 0;
     else if (sched && sched[0] == 't') ctx->sched_mode = 1;
     ctx->wave_slots = prop.multiProcessorCount * 4 * 8;
+    if (const char* g = getenv("PT_AUTO_GRID")) ctx->auto_grid = g[0] == '1';
+    if (const char* g = getenv("PT_GRID_RES")) ctx->grid_res_override = atoi(g);
     if (const char* k = getenv("PT_KEEP_UNREACHABLE")) ctx->keep_unreachable = k[0] == '1';
     if (const char* f = getenv("PT_SPLIT_FACTOR")) ctx->split_factor = (float)atof(f);  // for experiments
     *out_ctx = ctx;
@@ -530,6 +605,8 @@ PtStatus pt_build_accel(PtContext* ctx) {
     PT_REQUIRE(ctx->num_triangles > 0, PT_ERR_STATE, "no mesh uploaded");
     PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
     free_bvh(ctx);
+    ctx->grid_wanted = true;
+    ctx->records_valid = false;
     const int32_t n = ctx->num_triangles;
     if (n <= PT_BVH_LEAF_MAX) return PT_OK;  // a single leaf: the plain loop is the traversal
     PtBvhBuild& b = ctx->bvh;
@@ -571,7 +648,7 @@ PtStatus pt_build_accel(PtContext* ctx) {
 
 PtStatus pt_set_accel_mode(PtContext* ctx, PtAccelMode mode) {
     PT_REQUIRE(ctx != nullptr, PT_ERR_INVALID_ARGUMENT, "null context");
-    PT_REQUIRE(mode == PT_ACCEL_AUTO || mode == PT_ACCEL_BRUTE || mode == PT_ACCEL_BVH || mode == PT_ACCEL_CULL, PT_ERR_INVALID_ARGUMENT, "unknown accel mode %d", (int)mode);
+    PT_REQUIRE(mode == PT_ACCEL_AUTO || mode == PT_ACCEL_BRUTE || mode == PT_ACCEL_BVH || mode == PT_ACCEL_CULL || mode == PT_ACCEL_GRID, PT_ERR_INVALID_ARGUMENT, "unknown accel mode %d", (int)mode);
     ctx->accel_mode = mode;
     return PT_OK;
 }
@@ -706,7 +783,7 @@ PtStatus pt_dispatch(PtContext* ctx, int32_t first_sample, int32_t num_samples, 
             // tiles longer than the whole balanced kernel are split (measured on the 36-triangle scene: factor 0: 30.9 ms,
             // 1: 31.0, 2: 31.5, 4: 31.9); the hierarchy walk is latency-bound and gains from every additional wave
             // (968 triangles: 8.7 ms unsplit, 3.1 at factor 1, 2.6 at factor 4).
-            float factor = (p.bvh_nodes || p.bvh_nodes_abs) ? 4.0f : 1.0f;
+            float factor = (p.bvh_nodes || p.bvh_nodes_abs || p.grid_start) ? 4.0f : 1.0f;
             if (ctx->split_factor >= 0.f) factor = ctx->split_factor < (float)PT_MAX_SPLIT_FACTOR ? ctx->split_factor : (float)PT_MAX_SPLIT_FACTOR;
             int max_split = (ctx->sched_mode == 2 && num_samples > 1) ? (int)(factor * (float)ctx->wave_slots) : 0;
             const size_t slot_bytes = (size_t)num_samples * PT_TILE_THREADS * 16;
@@ -857,15 +934,17 @@ PtStatus pt_get_stats(PtContext* ctx, PtStats* out) {
     std::vector<unsigned long long> slots((size_t)PT_COUNTER_SLOTS * PT_COUNTER_STRIDE);
     PT_HIP_TRY(hipMemcpyAsync(slots.data(), ctx->d_counters, kCounterBytes, hipMemcpyDeviceToHost, ctx->stream));
     PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    unsigned long long c[5] = {0, 0, 0, 0, 0};
+    unsigned long long c[6] = {0, 0, 0, 0, 0, 0};
     for (size_t k = 0; k < PT_COUNTER_SLOTS; ++k)
-        for (int j = 0; j < 5; ++j) c[j] += slots[k * PT_COUNTER_STRIDE + j];
+        for (int j = 0; j < 6; ++j) c[j] += slots[k * PT_COUNTER_STRIDE + j];
     out->rays = c[0];
     out->rays_traced = c[4];
     out->samples = ctx->samples;
     out->lane_slots = c[1];
     out->bvh_node_fetches = c[2];
     out->bvh_triangle_fetches = c[3];
+    out->grid_triangle_tests = c[5];
+    out->grid_entries = ctx->grid_built ? ctx->grid_entries : 0;
     out->dispatches = ctx->dispatches;
     out->last_dispatch_ms = ctx->last_ms;
     out->total_dispatch_ms = ctx->total_ms;

@@ -1,0 +1,175 @@
+// Direction grid: an acceleration structure for rays that all start at one point.
+//
+// The reference shader never moves its ray origin (pathtracing.fs: every "ro = ..." in Shade is commented out), so every
+// closest-hit query -- camera rays and all bounce rays alike -- is "what does the camera position see in direction d".
+// That makes the search two-dimensional: the directions are cut into the cells of a cube map around the origin (6 faces
+// x R x R cells), and each cell lists the triangles that a direction inside it could hit. A query looks up its cell and
+// runs the exact triangle test on that list only: no hierarchy to walk, no chain of dependent fetches.
+//
+// Exactness: a cell's list must contain every triangle the exact fp32 test could accept for ANY direction of the cell.
+// The lists are built from the same origin-relative records the test uses (A = -ap, B = A + e1, C = A + e2): the triangle
+// is clipped to the face's pyramid (widened by a margin), projected, and entered into every cell its projected outline
+// may touch, with margins far above the angular slop of the fp32 test (about 1e-7 rad; margins are 1e-5 of the face
+// width plus a relative term). Triangles the origin sees from behind or edge-on (e2r <= 0) can never be hit and are
+// left out. Triangles in a list are tested in any order with the explicit lowest-index rule for equal distances.
+#include "pt_internal.h"
+
+#include <hipcub/hipcub.hpp>
+
+namespace {
+
+struct P3 { float x, y, z; };
+
+// face f = 2 * axis + (negative ? 1 : 0); local coordinates (u, v, w) with w > 0 inside the face's pyramid
+__device__ __forceinline__ P3 to_face(P3 p, int f) {
+    const int axis = f >> 1;
+    const float s = (f & 1) ? -1.0f : 1.0f;
+    P3 q;
+    if (axis == 0) { q.x = p.y; q.y = p.z; q.z = s * p.x; }
+    else if (axis == 1) { q.x = p.z; q.y = p.x; q.z = s * p.y; }
+    else { q.x = p.x; q.y = p.y; q.z = s * p.z; }
+    return q;
+}
+
+constexpr int kMaxPoly = 8;
+constexpr float kPyramidSlack = 1.0e-4f;  // the pyramid is widened by this fraction before clipping
+constexpr float kCellSlack = 2.0e-5f;     // in face coordinates (the face is 2 wide)
+
+// Sutherland-Hodgman step: keeps the part of the polygon with nx*x + ny*y + nz*z >= 0
+__device__ int clip_plane(const P3* in, int n, P3* out, float nx, float ny, float nz) {
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+        const P3 a = in[i], b = in[(i + 1) % n];
+        const float da = nx * a.x + ny * a.y + nz * a.z, db = nx * b.x + ny * b.y + nz * b.z;
+        if (da >= 0.f) out[m++] = a;
+        if ((da >= 0.f) != (db >= 0.f)) {
+            const float t = da / (da - db);
+            P3 c;
+            c.x = a.x + t * (b.x - a.x); c.y = a.y + t * (b.y - a.y); c.z = a.z + t * (b.z - a.z);
+            if (m < kMaxPoly) out[m++] = c;
+        }
+        if (m >= kMaxPoly) break;
+    }
+    return m;
+}
+
+// COUNT = false: list[cell_start[cell] + cursor[cell]++] = triangle; COUNT = true: cell_count[cell]++
+template <bool COUNT>
+__global__ __launch_bounds__(128) void grid_bin_triangles(const float4* __restrict__ tris, int n, int res, uint32_t* __restrict__ cell_count,
+                                                          const uint32_t* __restrict__ cell_start, uint32_t* __restrict__ list) {
+    const int job = blockIdx.x * blockDim.x + threadIdx.x;
+    if (job >= n * 6) return;
+    const int i = job / 6, f = job % 6;
+    const float4 r0 = tris[4 * (size_t)i], r1 = tris[4 * (size_t)i + 1], r2 = tris[4 * (size_t)i + 2], r3 = tris[4 * (size_t)i + 3];
+    if (!(r3.x > 0.0f)) return;  // e2r <= 0 (or NaN): no ray from the origin can be accepted
+    // record: e1.xyz e2.x | e2.yz ap.xy | ap.z r.xyz | e2r - - id
+    P3 A, B, C;
+    A.x = -r1.z; A.y = -r1.w; A.z = -r2.x;
+    B.x = A.x + r0.x; B.y = A.y + r0.y; B.z = A.z + r0.z;
+    C.x = A.x + r0.w; C.y = A.y + r1.x; C.z = A.z + r1.y;
+    P3 pa[kMaxPoly], pb[kMaxPoly];
+    pa[0] = to_face(A, f); pa[1] = to_face(B, f); pa[2] = to_face(C, f);
+    // cheap reject: the whole triangle behind the face's apex plane
+    if (pa[0].z <= 0.f && pa[1].z <= 0.f && pa[2].z <= 0.f) return;
+    const float k = 1.0f + kPyramidSlack;
+    int m = clip_plane(pa, 3, pb, -1.f, 0.f, k);   // k*w - u >= 0
+    m = clip_plane(pb, m, pa, 1.f, 0.f, k);        // k*w + u >= 0
+    m = clip_plane(pa, m, pb, 0.f, -1.f, k);
+    m = clip_plane(pb, m, pa, 0.f, 1.f, k);
+    if (m < 1) return;
+    // project; bounding box in face coordinates
+    float pu[kMaxPoly], pv[kMaxPoly];
+    float u0 = 4.f, u1 = -4.f, v0 = 4.f, v1 = -4.f;
+    int valid = 0;
+    for (int q = 0; q < m; ++q) {
+        if (!(pa[q].z > 0.f)) continue;  // only the apex itself can have w = 0 after clipping
+        const float iw = 1.0f / pa[q].z;
+        pu[valid] = pa[q].x * iw; pv[valid] = pa[q].y * iw;
+        u0 = fminf(u0, pu[valid]); u1 = fmaxf(u1, pu[valid]);
+        v0 = fminf(v0, pv[valid]); v1 = fmaxf(v1, pv[valid]);
+        ++valid;
+    }
+    if (valid == 0) return;
+    m = valid;
+    // How far outside its true outline can the fp32 test still accept this triangle? Each of its three conditions is a
+    // plane through the origin and one edge; the computed side of a direction is off by a few eps x S over the doubled
+    // area of the triangle (origin, edge), S bounding the magnitudes that enter the sums. That is ~1e-7 rad for ordinary
+    // views and grows only when an edge points at the origin. x4: radians -> face coordinates, both axes.
+    const float lA = sqrtf(A.x * A.x + A.y * A.y + A.z * A.z), l1 = sqrtf(r0.x * r0.x + r0.y * r0.y + r0.z * r0.z),
+                l2 = sqrtf(r0.w * r0.w + r1.x * r1.x + r1.y * r1.y);
+    auto cross_len = [](P3 a, P3 b) {
+        const float x = a.y * b.z - a.z * b.y, y = a.z * b.x - a.x * b.z, z = a.x * b.y - a.y * b.x;
+        return sqrtf(x * x + y * y + z * z);
+    };
+    const float S = lA * (l1 + l2) + l1 * l2;
+    const float weakest = fminf(cross_len(A, B), fminf(cross_len(A, C), cross_len(B, C)));
+    const float fuzz = weakest > 0.f ? fminf(4.0f * 16.0f * 5.97e-8f * S / weakest, 4.0f) : 4.0f;
+    const float slack = kCellSlack + fuzz + 1.0e-5f * fmaxf(fmaxf(fabsf(u0), fabsf(u1)), fmaxf(fabsf(v0), fabsf(v1)));
+    const float half = 0.5f * (float)res;
+    auto cell_of = [half, res](float c) { const int q = (int)floorf((c + 1.0f) * half); return q < 0 ? 0 : (q >= res ? res - 1 : q); };
+    if (u1 + slack < -1.f || u0 - slack > 1.f || v1 + slack < -1.f || v0 - slack > 1.f) return;
+    const int iu0 = cell_of(u0 - slack), iu1 = cell_of(u1 + slack), iv0 = cell_of(v0 - slack), iv1 = cell_of(v1 + slack);
+    // outline test: a cell wholly outside one edge of the (convex) projected polygon cannot be touched. Only when the
+    // polygon has a safe area; a sliver falls back to its bounding box.
+    float area2 = 0.f;
+    for (int q = 0; q < m; ++q) { const int q2 = (q + 1) % m; area2 += pu[q] * pv[q2] - pu[q2] * pv[q]; }
+    const float extent = fmaxf(u1 - u0, v1 - v0);
+    const bool use_edges = m >= 3 && fabsf(area2) > 1.0e-3f * extent * extent && extent > 0.f;
+    const float orient = area2 > 0.f ? 1.f : -1.f;
+    const float cw = 2.0f / (float)res;
+    const uint32_t id = (uint32_t)i;
+    for (int iv = iv0; iv <= iv1; ++iv) {
+        const float cv0 = -1.f + cw * (float)iv - slack, cv1 = -1.f + cw * (float)(iv + 1) + slack;
+        for (int iu = iu0; iu <= iu1; ++iu) {
+            bool touch = true;
+            if (use_edges) {
+                const float cu0 = -1.f + cw * (float)iu - slack, cu1 = -1.f + cw * (float)(iu + 1) + slack;
+                for (int q = 0; q < m && touch; ++q) {
+                    const int q2 = (q + 1) % m;
+                    // inward normal of edge q -> q2 for a counter-clockwise polygon: (-dy, dx)
+                    const float nx = -(pv[q2] - pv[q]) * orient, ny = (pu[q2] - pu[q]) * orient;
+                    // the cell corner farthest along the inward normal
+                    const float cx = nx > 0.f ? cu1 : cu0, cy = ny > 0.f ? cv1 : cv0;
+                    const float d = nx * (cx - pu[q]) + ny * (cy - pv[q]);
+                    const float len = fabsf(nx) + fabsf(ny);
+                    if (d < -1.0e-5f * len) touch = false;  // even that corner is outside this edge
+                }
+            }
+            if (!touch) continue;
+            const size_t cell = ((size_t)f * res + iv) * res + iu;
+            if (COUNT) atomicAdd(&cell_count[cell], 1u);
+            else list[cell_start[cell] + atomicAdd(&cell_count[cell], 1u)] = id;
+        }
+    }
+}
+
+}  // namespace
+
+size_t pt_grid_scan_temp_bytes(size_t cells) {
+    size_t bytes = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)(cells + 1), nullptr);
+    return bytes;
+}
+
+hipError_t pt_grid_count(const PtGridBuild& g, const float* tris, int32_t n, hipStream_t stream) {
+    const size_t cells = (size_t)6 * g.res * g.res;
+    hipError_t e = hipMemsetAsync(g.cell_count, 0, (cells + 1) * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    const int jobs = n * 6;
+    hipLaunchKernelGGL(grid_bin_triangles<true>, dim3((jobs + 127) / 128), dim3(128), 0, stream, reinterpret_cast<const float4*>(tris), n, g.res,
+                       g.cell_count, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+    size_t bytes = g.scan_tmp_bytes;
+    e = hipcub::DeviceScan::ExclusiveSum(g.scan_tmp, bytes, g.cell_count, g.cell_start, (int)(cells + 1), stream);
+    if (e != hipSuccess) return e;
+    return hipGetLastError();
+}
+
+hipError_t pt_grid_fill(const PtGridBuild& g, const float* tris, int32_t n, hipStream_t stream) {
+    const size_t cells = (size_t)6 * g.res * g.res;
+    hipError_t e = hipMemsetAsync(g.cell_count, 0, (cells + 1) * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    const int jobs = n * 6;
+    hipLaunchKernelGGL(grid_bin_triangles<false>, dim3((jobs + 127) / 128), dim3(128), 0, stream, reinterpret_cast<const float4*>(tris), n, g.res,
+                       g.cell_count, g.cell_start, g.list);
+    return hipGetLastError();
+}

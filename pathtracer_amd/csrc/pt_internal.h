@@ -69,6 +69,23 @@ struct PtBvhBuild {
     int* sorted_ids;              // n + PT_TRI_PAD
 };
 
+// Direction grid (pt_grid.hip): for rays that all start at the camera, cube-map cells -> triangles a direction of the
+// cell could hit. cell_start has 6*res*res + 1 entries (exclusive prefix sums; the last is the list length).
+struct PtGridBuild {
+    int32_t res;
+    uint32_t* cell_count;   // 6*res*res + 1: counts during the build, fill cursors afterwards
+    uint32_t* cell_start;   // 6*res*res + 1
+    uint32_t* list;         // triangle indices
+    size_t list_capacity;   // entries
+    void* scan_tmp;
+    size_t scan_tmp_bytes;
+};
+size_t pt_grid_scan_temp_bytes(size_t cells);
+// counts the entries of every cell and leaves their prefix sums in cell_start (read cell_start[cells] for the list length)
+hipError_t pt_grid_count(const PtGridBuild& g, const float* tris, int32_t n, hipStream_t stream);
+// fills list (capacity must cover cell_start[cells])
+hipError_t pt_grid_fill(const PtGridBuild& g, const float* tris, int32_t n, hipStream_t stream);
+
 size_t pt_bvh_sort_temp_bytes(int32_t n);
 // Morton codes, sort, hierarchy, boxes. Synchronises the stream (a handful of times) to learn when the refit is done.
 hipError_t pt_bvh_build_topology(const PtBvhBuild& b, hipStream_t stream, int32_t* out_passes);
@@ -114,6 +131,10 @@ struct PtKernelParams {
     const float* vnormals;              // num_triangles x 9: the three vertex normals (na, nb, nc)
     const float* gnormals;              // num_triangles x 3: normalize(cross(e1, e2))
     const float* cull;                  // num_triangles x PT_CULL_FLOATS, or null = no wave-level culling
+    const uint32_t* grid_start;         // direction grid: 6*res*res + 1 prefix sums, or null
+    const uint32_t* grid_list;          // triangle indices of the cells
+    const float* grid_tris;             // all records (origin-relative), indexed by triangle
+    int32_t grid_res;
     const uint32_t* live_count;         // device scalar: records in `tris` when it is the compacted array; null = num_triangles
     const float* tris_abs;              // num_triangles x PT_TRI_FLOATS: a, e1, e2 (for rays with their own origin)
     const float* materials;             // num_materials x (r, g, b, e)

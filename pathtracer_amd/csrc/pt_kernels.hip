@@ -449,6 +449,54 @@ __device__ __forceinline__ Hit intersect_bvh(const PtKernelParams& p, v3 ro, v3 
     return h;
 }
 
+// Direction-grid query (see pt_grid.hip): the cell of the ray's direction lists the triangles it can hit at all. Every
+// lane walks its own list (lanes of a wave look in different cells), records come through per-lane vector loads; the
+// index of the next entry is fetched while the current triangle is tested. Same exact test, explicit lowest-index rule.
+__device__ __forceinline__ Hit intersect_grid(const PtKernelParams& p, v3 rd, unsigned& tests) {
+    Hit h;
+    h.t = 1.0e38f; h.id = -1; h.u = 0.f; h.v = 0.f; h.ood = 0.f;
+    const float ax = __builtin_fabsf(rd.x), ay = __builtin_fabsf(rd.y), az = __builtin_fabsf(rd.z);
+    int face;
+    float fu, fv, fw;
+    if (ax >= ay && ax >= az) { face = rd.x < 0.f ? 1 : 0; fu = rd.y; fv = rd.z; fw = ax; }
+    else if (ay >= az) { face = rd.y < 0.f ? 3 : 2; fu = rd.z; fv = rd.x; fw = ay; }
+    else { face = rd.z < 0.f ? 5 : 4; fu = rd.x; fv = rd.y; fw = az; }
+    if (!(fw > 0.f)) return h;  // a zero or NaN direction hits nothing
+    const float iw = __builtin_amdgcn_rcpf(fw);
+    const int res = p.grid_res;
+    const float half = 0.5f * (float)res;
+    int iu = (int)__builtin_floorf((fu * iw + 1.0f) * half), iv = (int)__builtin_floorf((fv * iw + 1.0f) * half);
+    iu = iu < 0 ? 0 : (iu >= res ? res - 1 : iu);
+    iv = iv < 0 ? 0 : (iv >= res ? res - 1 : iv);
+    const size_t cell = ((size_t)face * res + iv) * res + iu;
+    const uint32_t begin = p.grid_start[cell], end = p.grid_start[cell + 1];
+    const float4* __restrict__ recs = reinterpret_cast<const float4*>(p.grid_tris);
+    uint32_t next = begin < end ? p.grid_list[begin] : 0u;
+    for (uint32_t k = begin; k < end; ++k) {
+        const uint32_t tri = next;
+        if (k + 1 < end) next = p.grid_list[k + 1];
+        TriRec t;
+        t.a = recs[4 * (size_t)tri]; t.b = recs[4 * (size_t)tri + 1]; t.c = recs[4 * (size_t)tri + 2]; t.d = recs[4 * (size_t)tri + 3];
+        const v3 e1 = V(t.a.x, t.a.y, t.a.z);
+        const v3 e2 = V(t.a.w, t.b.x, t.b.y);
+        const v3 q = cross3(rd, e2);
+        const float det = dot3(e1, q);
+        const v3 ap = V(t.b.z, t.b.w, t.c.x);
+        const v3 r = V(t.c.y, t.c.z, t.c.w);
+        const float u = dot3(ap, q);
+        const float v = dot3(rd, r);
+        if ((det >= 0.0001f) & (u >= 0.0f) & (v >= 0.0f) & ((u + v) <= det)) {
+            const float ood = 1.0f / det;
+            const float tt = t.d.x * ood;
+            if (tt > 0.0f && (tt < h.t || (tt == h.t && (int)tri < h.id))) {
+                h.t = tt; h.id = (int)tri; h.u = u; h.v = v; h.ood = ood;
+            }
+        }
+        ++tests;
+    }
+    return h;
+}
+
 // fs:83-121. `ro` is the camera position for every ray. Returns the hit normal through `n`.
 __device__ __forceinline__ Hit intersect_world(const float* __restrict__ spheres, v3 ro, v3 rd, v3& n) {
     Hit h;
@@ -616,6 +664,7 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
     unsigned traced = 0;  // queries this lane actually evaluated
     unsigned trips = 0;   // queries evaluated by the WAVE: trips x 64 lane slots were spent for `traced` useful ones
     unsigned node_visits = 0, tri_tests = 0;  // per WAVE (the BVH walk is wave-uniform): records fetched
+    unsigned lane_tests = 0;                  // per LANE (direction grid): triangles tested
 
     CullRec cull0;
     if (KIND == 3) cull0 = load_cull(reinterpret_cast<const float4*>(p.cull), threadIdx.x & 63, p.num_triangles);
@@ -630,7 +679,8 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
         } else if (want) {
             if (KIND == 0) h = intersect_world(p.spheres, o, d, n);
             else if (KIND == 1) h = MATERIALS ? intersect_mesh_from(p.tris_abs, p.num_triangles, o, d) : intersect_mesh(p.tris, live_triangles(p), d);
-            else h = intersect_bvh<MATERIALS>(p, o, d, s_stack[threadIdx.x >> 6], node_visits, tri_tests);
+            else if (KIND == 2) h = intersect_bvh<MATERIALS>(p, o, d, s_stack[threadIdx.x >> 6], node_visits, tri_tests);
+            else h = intersect_grid(p, d, lane_tests);
         }
         const bool hit = want && h.id >= 0;
         if (hit && KIND != 0) n = mesh_normal(p, h);
@@ -729,6 +779,7 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
         reinterpret_cast<float4*>(p.dst)[pix] = make_float4(mr, mg, mb, alpha);
     }
     const unsigned long long wave_rays = wave_sum(rays), wave_traced = wave_sum(traced);
+    const unsigned long long wave_tests = KIND == 4 ? wave_sum(lane_tests) : 0ull;
     const unsigned wave_trips = __builtin_amdgcn_readfirstlane(__reduce_max_trips(trips));
     if ((threadIdx.x & 63) == 0 && wave_rays) {
         unsigned long long* counters = p.counters + (size_t)(blockIdx.x % PT_COUNTER_SLOTS) * PT_COUNTER_STRIDE;
@@ -740,12 +791,14 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
         if (p.tile_cost) {
             unsigned cost = wave_trips;
             if (KIND == 2) cost = 8u * wave_trips + __builtin_amdgcn_readfirstlane(node_visits) + __builtin_amdgcn_readfirstlane(tri_tests);
+            if (KIND == 4) cost = 8u * wave_trips + (unsigned)(wave_tests >> 4);
             atomicAdd(&p.tile_cost[tile], cost);
         }
-        if (KIND >= 2) {
+        if (KIND == 2 || KIND == 3) {
             atomicAdd(&counters[2], (unsigned long long)__builtin_amdgcn_readfirstlane(node_visits));
             atomicAdd(&counters[3], (unsigned long long)__builtin_amdgcn_readfirstlane(tri_tests));
         }
+        if (KIND == 4) atomicAdd(&counters[5], wave_tests);
     }
 }
 
@@ -754,7 +807,7 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_primary_kernel(const PtKer
     __shared__ uint32_t s_stack[KIND == 2 ? PT_TILE_WAVES : 1][KIND == 2 ? PT_BVH_STACK : 1];
     int x, y;
     const bool in_window = pixel_of_lane(p, (int)blockIdx.x, x, y);
-    if (KIND < 2 && !in_window) return;  // the BVH walk and the cull step are per wave: every lane stays
+    if ((KIND < 2 || KIND == 4) && !in_window) return;  // the BVH walk and the cull step are per wave: every lane stays
     const size_t pix = (size_t)y * p.width + x;
     const v3 ro = V(p.ro[0], p.ro[1], p.ro[2]);
     const v3 rd = primary_direction(p, (float)x + 0.5f, (float)y + 0.5f);
@@ -765,6 +818,7 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_primary_kernel(const PtKer
     unsigned nv = 0, tt = 0;
     if (KIND == 2) h = intersect_bvh<false>(p, ro, rd, s_stack[threadIdx.x >> 6], nv, tt);
     if (KIND == 3) h = intersect_mesh_culled(p, rd, in_window, load_cull(reinterpret_cast<const float4*>(p.cull), threadIdx.x & 63, p.num_triangles), tt);
+    if (KIND == 4) h = intersect_grid(p, rd, tt);
     if (!in_window) return;
     if (p.out_ids) p.out_ids[pix] = h.id;
     if (p.out_t) p.out_t[pix] = h.t;
@@ -1050,6 +1104,7 @@ hipError_t pt_launch_render(const PtKernelParams& p, int program_kind, hipStream
         if (p.bvh_nodes_abs) hipLaunchKernelGGL((pt_render_kernel<2, true>), grid, block, 0, stream, p);
         else hipLaunchKernelGGL((pt_render_kernel<1, true>), grid, block, 0, stream, p);
     }
+    else if (p.grid_start) hipLaunchKernelGGL((pt_render_kernel<4, false>), grid, block, 0, stream, p);
     else if (p.bvh_nodes) hipLaunchKernelGGL((pt_render_kernel<2, false>), grid, block, 0, stream, p);
     else if (p.cull) hipLaunchKernelGGL((pt_render_kernel<3, false>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL((pt_render_kernel<1, false>), grid, block, 0, stream, p);
@@ -1061,6 +1116,7 @@ hipError_t pt_launch_render(const PtKernelParams& p, int program_kind, hipStream
 hipError_t pt_launch_primary(const PtKernelParams& p, int program_kind, hipStream_t stream) {
     if (p.win_w <= 0 || p.win_h <= 0) return hipSuccess;
     if (program_kind == 0) hipLaunchKernelGGL(pt_primary_kernel<0>, dim3(window_tiles(p)), dim3(PT_TILE_THREADS), 0, stream, p);
+    else if (p.grid_start) hipLaunchKernelGGL(pt_primary_kernel<4>, dim3(window_tiles(p)), dim3(PT_TILE_THREADS), 0, stream, p);
     else if (p.bvh_nodes) hipLaunchKernelGGL(pt_primary_kernel<2>, dim3(window_tiles(p)), dim3(PT_TILE_THREADS), 0, stream, p);
     else if (p.cull) hipLaunchKernelGGL(pt_primary_kernel<3>, dim3(window_tiles(p)), dim3(PT_TILE_THREADS), 0, stream, p);
     else hipLaunchKernelGGL(pt_primary_kernel<1>, dim3(window_tiles(p)), dim3(PT_TILE_THREADS), 0, stream, p);

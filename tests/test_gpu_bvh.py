@@ -33,7 +33,7 @@ def both_modes(t, verts, idx, cam, W, H, normal_mode, spp=3, window=None):
     t.set_uniforms(cam, len(idx), 10)
     t.build_accel()
     res = {}
-    for name, mode in (("brute", capi.ACCEL_BRUTE), ("bvh", capi.ACCEL_BVH), ("cull", capi.ACCEL_CULL)):
+    for name, mode in (("brute", capi.ACCEL_BRUTE), ("bvh", capi.ACCEL_BVH), ("cull", capi.ACCEL_CULL), ("grid", capi.ACCEL_GRID)):
         t.set_accel_mode(mode)
         t.target_clear()
         t.reset_stats()
@@ -49,7 +49,7 @@ def both_modes(t, verts, idx, cam, W, H, normal_mode, spp=3, window=None):
 
 def assert_same(res):
     b = res["brute"]
-    for other in ("bvh", "cull"):
+    for other in ("bvh", "cull", "grid"):
         a = res[other]
         assert np.array_equal(a[0], b[0]), f"{other}: {(a[0] != b[0]).sum()} primary ids differ"
         assert n_bit_mismatch(a[1], b[1]) == 0, other

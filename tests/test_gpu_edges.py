@@ -54,7 +54,7 @@ def test_small_and_ragged_images(tracer, size, kind):
     tracer.program_destroy(prog)
 
 
-@pytest.mark.parametrize("accel", [1, 2])
+@pytest.mark.parametrize("accel", [1, 2, 4])
 @pytest.mark.parametrize("window", [(3, 5, 1, 1), (5, 9, 11, 7), (0, 0, 128, 1), (127, 0, 1, 128), (17, 33, 90, 41)])
 def test_windows_that_cut_tiles(tracer, window, accel):
     """Only the window is rendered; what lies outside keeps the clear value. Twice, so that the second dispatch runs from a
@@ -121,7 +121,7 @@ def test_no_triangles_traced(tracer):
     tracer.program_destroy(prog)
 
 
-@pytest.mark.parametrize("accel", [1, 2])
+@pytest.mark.parametrize("accel", [1, 2, 4])
 def test_degenerate_and_duplicated_triangles(tracer, accel):
     """Zero-area triangles (collapsed to a point, to a line), exact duplicates (the lower index must win) and triangles
     seen edge-on, mixed into a random soup."""

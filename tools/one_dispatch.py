@@ -17,7 +17,7 @@ def main():
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--lib", default=None)
-    ap.add_argument("--accel", default="auto", choices=["auto", "brute", "bvh", "cull"])
+    ap.add_argument("--accel", default="auto", choices=["auto", "brute", "bvh", "cull", "grid"])
     ap.add_argument("--shading", default="reference", choices=["reference", "materials"])
     ap.add_argument("--no-reuse", action="store_true", help="evaluate the camera ray for every sample, like the shader")
     args = ap.parse_args()
@@ -36,7 +36,7 @@ def main():
         t.set_accel_mode(2)
     else:
         build_s = 0.0
-        t.set_accel_mode({"brute": 1, "cull": 3, "auto": 0}[args.accel])
+        t.set_accel_mode({"brute": 1, "cull": 3, "auto": 0, "grid": 4}[args.accel])
     t.set_primary_reuse(not args.no_reuse)
     t.enable_timing(True)
     t.dispatch(1, 1, 1)
@@ -55,6 +55,7 @@ def main():
                       "Gsamples_per_s": st["samples"] / st["dispatches"] / ms * 1e-6, "primary_reuse": not args.no_reuse,
                       "rays_per_sample": st["rays"] / st["samples"], "lane_utilisation": st["rays_traced"] / max(1, st["lane_slots"]),
                       "triangle_records_per_wave_ray": st["bvh_triangle_fetches"] * 64 / st["lane_slots"],
+                      "grid_tests_per_traced_ray": st["grid_triangle_tests"] / max(1, st["rays_traced"]), "grid_entries": st["grid_entries"],
                       "node_records_per_wave_ray": st["bvh_node_fetches"] * 64 / st["lane_slots"]}))
     t.close()
 
