@@ -56,8 +56,9 @@ typedef enum PtNormalMode {
 
 /* How the closest mesh hit is searched. Results are identical in every mode (same triangle ids, same distances). */
 typedef enum PtAccelMode {
-    PT_ACCEL_AUTO = 0,  /* the fastest measured choice: the plain loop for small meshes, the LBVH (once built) above 48 triangles
-                           (128 in PT_SHADE_MATERIALS) */
+    PT_ACCEL_AUTO = 0,  /* the fastest measured choice. After pt_build_accel: the direction grid for the reference shading (rays
+                           all start at the camera), the LBVH above 128 triangles for PT_SHADE_MATERIALS. Without
+                           pt_build_accel, or when fewer triangles are traced than uploaded: the plain loop */
     PT_ACCEL_BRUTE = 1, /* the shader's own loop over all triangles in index order, pathtracing.fs:129 */
     PT_ACCEL_BVH = 2,   /* require the LBVH: pt_dispatch fails with PT_ERR_STATE when none is built */
     PT_ACCEL_GRID = 4,  /* require the direction grid (built by pt_build_accel, rebuilt when the camera position changes): the

@@ -105,7 +105,7 @@ struct PtContext {
     int32_t wave_slots = 0;               // waves the device holds at once (CUs x 4 SIMDs x 8)
     float split_factor = -1.f;            // < 0: chosen per kernel family, see pt_dispatch
     bool primary_reuse = true;
-    bool auto_grid = false;               // PT_AUTO_GRID=1: PT_ACCEL_AUTO prefers the direction grid
+    bool auto_grid = true;                // PT_AUTO_GRID=0: PT_ACCEL_AUTO never picks the direction grid (for comparisons)
     bool keep_unreachable = false;        // PT_KEEP_UNREACHABLE=1: the loop walks all records (to measure the compaction)
     int32_t sched_win[4] = {-1, -1, -1, -1};  // window the costs were measured for
     bool sched_have_cost = false;
@@ -197,7 +197,7 @@ void free_bvh(PtContext* ctx) {
 
 void free_grid(PtContext* ctx) {
     PtGridBuild& g = ctx->grid;
-    void* ptrs[] = {g.cell_count, g.cell_start, g.list, g.scan_tmp};
+    void* ptrs[] = {g.cell_count, g.cell_start, g.list, g.scan_tmp, g.big_jobs, g.big_count};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     g = PtGridBuild{};
@@ -223,6 +223,9 @@ PtStatus build_grid(PtContext* ctx) {
         PT_HIP_TRY(hipMalloc(&g.cell_count, (cells + 1) * sizeof(uint32_t)));
         PT_HIP_TRY(hipMalloc(&g.cell_start, (cells + 1) * sizeof(uint32_t)));
         PT_HIP_TRY(hipMalloc(&g.scan_tmp, g.scan_tmp_bytes ? g.scan_tmp_bytes : 16));
+        g.big_capacity = (uint32_t)std::min<size_t>((size_t)ctx->num_triangles * 6, (size_t)4 << 20);
+        PT_HIP_TRY(hipMalloc(&g.big_jobs, (size_t)g.big_capacity * sizeof(uint32_t)));
+        PT_HIP_TRY(hipMalloc(&g.big_count, sizeof(uint32_t)));
     }
     ctx->grid_built = false;
     PT_HIP_TRY(pt_grid_count(g, ctx->d_tris, ctx->num_triangles, ctx->stream));
@@ -338,7 +341,7 @@ PtStatus fill_params(PtContext* ctx, PtKernelParams* p, const Program** prog_out
         PT_REQUIRE(ctx->accel_mode != PT_ACCEL_GRID || (ctx->grid_built && ctx->shading_mode == PT_SHADE_REFERENCE && u.num_triangles == ctx->num_triangles),
                    PT_ERR_STATE, "PT_ACCEL_GRID needs pt_build_accel, PT_SHADE_REFERENCE and u_NumTriangles = all %d triangles", ctx->num_triangles);
         const bool use_grid = ctx->grid_built && ctx->shading_mode == PT_SHADE_REFERENCE && u.num_triangles == ctx->num_triangles &&
-                              (ctx->accel_mode == PT_ACCEL_GRID || (ctx->accel_mode == PT_ACCEL_AUTO && ctx->auto_grid));
+                              (ctx->accel_mode == PT_ACCEL_GRID || (ctx->accel_mode == PT_ACCEL_AUTO && ctx->auto_grid));  // measured faster at every size
         if (use_grid) {
             p->grid_start = ctx->grid.cell_start;
             p->grid_list = ctx->grid.list;
@@ -432,7 +435,7 @@ PtStatus pt_create(int32_t device, PtContext** out_ctx) {
     if (sched && sched[0] == '0') ctx->sched_mode = 0;
     else if (sched && sched[0] == 't') ctx->sched_mode = 1;
     ctx->wave_slots = prop.multiProcessorCount * 4 * 8;
-    if (const char* g = getenv("PT_AUTO_GRID")) ctx->auto_grid = g[0] == '1';
+    if (const char* g = getenv("PT_AUTO_GRID")) ctx->auto_grid = g[0] != '0';
     if (const char* g = getenv("PT_GRID_RES")) ctx->grid_res_override = atoi(g);
     if (const char* k = getenv("PT_KEEP_UNREACHABLE")) ctx->keep_unreachable = k[0] == '1';
     if (const char* f = getenv("PT_SPLIT_FACTOR")) ctx->split_factor = (float)atof(f);  // for experiments
@@ -783,7 +786,8 @@ PtStatus pt_dispatch(PtContext* ctx, int32_t first_sample, int32_t num_samples, 
             // tiles longer than the whole balanced kernel are split (measured on the 36-triangle scene: factor 0: 30.9 ms,
             // 1: 31.0, 2: 31.5, 4: 31.9); the hierarchy walk is latency-bound and gains from every additional wave
             // (968 triangles: 8.7 ms unsplit, 3.1 at factor 1, 2.6 at factor 4).
-            float factor = (p.bvh_nodes || p.bvh_nodes_abs || p.grid_start) ? 4.0f : 1.0f;
+            float factor = (p.bvh_nodes || p.bvh_nodes_abs) ? 4.0f : 1.0f;  // direction grid, 1080p Cornell: 9.6 ms at 0 and 1, 10.1 at 2, 10.6 at 4;
+                                                                            // suzanne 0.87 / 0.54 / 0.50 / 0.51
             if (ctx->split_factor >= 0.f) factor = ctx->split_factor < (float)PT_MAX_SPLIT_FACTOR ? ctx->split_factor : (float)PT_MAX_SPLIT_FACTOR;
             int max_split = (ctx->sched_mode == 2 && num_samples > 1) ? (int)(factor * (float)ctx->wave_slots) : 0;
             const size_t slot_bytes = (size_t)num_samples * PT_TILE_THREADS * 16;

@@ -53,15 +53,18 @@ __device__ int clip_plane(const P3* in, int n, P3* out, float nx, float ny, floa
     return m;
 }
 
-// COUNT = false: list[cell_start[cell] + cursor[cell]++] = triangle; COUNT = true: cell_count[cell]++
-template <bool COUNT>
-__global__ __launch_bounds__(128) void grid_bin_triangles(const float4* __restrict__ tris, int n, int res, uint32_t* __restrict__ cell_count,
-                                                          const uint32_t* __restrict__ cell_start, uint32_t* __restrict__ list) {
-    const int job = blockIdx.x * blockDim.x + threadIdx.x;
-    if (job >= n * 6) return;
-    const int i = job / 6, f = job % 6;
+// One (triangle, face) job: the triangle clipped to the face's pyramid and projected; which cells its outline may touch.
+struct FaceJob {
+    float pu[kMaxPoly], pv[kMaxPoly];
+    int m;                      // polygon vertices
+    int iu0, iu1, iv0, iv1;     // cell range of the bounding box
+    float slack, orient;
+    bool use_edges;
+};
+
+__device__ bool setup_job(const float4* __restrict__ tris, int i, int f, int res, FaceJob& job) {
     const float4 r0 = tris[4 * (size_t)i], r1 = tris[4 * (size_t)i + 1], r2 = tris[4 * (size_t)i + 2], r3 = tris[4 * (size_t)i + 3];
-    if (!(r3.x > 0.0f)) return;  // e2r <= 0 (or NaN): no ray from the origin can be accepted
+    if (!(r3.x > 0.0f)) return false;  // e2r <= 0 (or NaN): no ray from the origin can be accepted
     // record: e1.xyz e2.x | e2.yz ap.xy | ap.z r.xyz | e2r - - id
     P3 A, B, C;
     A.x = -r1.z; A.y = -r1.w; A.z = -r2.x;
@@ -70,26 +73,25 @@ __global__ __launch_bounds__(128) void grid_bin_triangles(const float4* __restri
     P3 pa[kMaxPoly], pb[kMaxPoly];
     pa[0] = to_face(A, f); pa[1] = to_face(B, f); pa[2] = to_face(C, f);
     // cheap reject: the whole triangle behind the face's apex plane
-    if (pa[0].z <= 0.f && pa[1].z <= 0.f && pa[2].z <= 0.f) return;
+    if (pa[0].z <= 0.f && pa[1].z <= 0.f && pa[2].z <= 0.f) return false;
     const float k = 1.0f + kPyramidSlack;
     int m = clip_plane(pa, 3, pb, -1.f, 0.f, k);   // k*w - u >= 0
     m = clip_plane(pb, m, pa, 1.f, 0.f, k);        // k*w + u >= 0
     m = clip_plane(pa, m, pb, 0.f, -1.f, k);
     m = clip_plane(pb, m, pa, 0.f, 1.f, k);
-    if (m < 1) return;
+    if (m < 1) return false;
     // project; bounding box in face coordinates
-    float pu[kMaxPoly], pv[kMaxPoly];
     float u0 = 4.f, u1 = -4.f, v0 = 4.f, v1 = -4.f;
     int valid = 0;
     for (int q = 0; q < m; ++q) {
         if (!(pa[q].z > 0.f)) continue;  // only the apex itself can have w = 0 after clipping
         const float iw = 1.0f / pa[q].z;
-        pu[valid] = pa[q].x * iw; pv[valid] = pa[q].y * iw;
-        u0 = fminf(u0, pu[valid]); u1 = fmaxf(u1, pu[valid]);
-        v0 = fminf(v0, pv[valid]); v1 = fmaxf(v1, pv[valid]);
+        job.pu[valid] = pa[q].x * iw; job.pv[valid] = pa[q].y * iw;
+        u0 = fminf(u0, job.pu[valid]); u1 = fmaxf(u1, job.pu[valid]);
+        v0 = fminf(v0, job.pv[valid]); v1 = fmaxf(v1, job.pv[valid]);
         ++valid;
     }
-    if (valid == 0) return;
+    if (valid == 0) return false;
     m = valid;
     // How far outside its true outline can the fp32 test still accept this triangle? Each of its three conditions is a
     // plane through the origin and one edge; the computed side of a direction is off by a few eps x S over the doubled
@@ -107,40 +109,103 @@ __global__ __launch_bounds__(128) void grid_bin_triangles(const float4* __restri
     const float slack = kCellSlack + fuzz + 1.0e-5f * fmaxf(fmaxf(fabsf(u0), fabsf(u1)), fmaxf(fabsf(v0), fabsf(v1)));
     const float half = 0.5f * (float)res;
     auto cell_of = [half, res](float c) { const int q = (int)floorf((c + 1.0f) * half); return q < 0 ? 0 : (q >= res ? res - 1 : q); };
-    if (u1 + slack < -1.f || u0 - slack > 1.f || v1 + slack < -1.f || v0 - slack > 1.f) return;
-    const int iu0 = cell_of(u0 - slack), iu1 = cell_of(u1 + slack), iv0 = cell_of(v0 - slack), iv1 = cell_of(v1 + slack);
+    if (u1 + slack < -1.f || u0 - slack > 1.f || v1 + slack < -1.f || v0 - slack > 1.f) return false;
+    job.iu0 = cell_of(u0 - slack); job.iu1 = cell_of(u1 + slack); job.iv0 = cell_of(v0 - slack); job.iv1 = cell_of(v1 + slack);
     // outline test: a cell wholly outside one edge of the (convex) projected polygon cannot be touched. Only when the
     // polygon has a safe area; a sliver falls back to its bounding box.
     float area2 = 0.f;
-    for (int q = 0; q < m; ++q) { const int q2 = (q + 1) % m; area2 += pu[q] * pv[q2] - pu[q2] * pv[q]; }
+    for (int q = 0; q < m; ++q) { const int q2 = (q + 1) % m; area2 += job.pu[q] * job.pv[q2] - job.pu[q2] * job.pv[q]; }
     const float extent = fmaxf(u1 - u0, v1 - v0);
-    const bool use_edges = m >= 3 && fabsf(area2) > 1.0e-3f * extent * extent && extent > 0.f;
-    const float orient = area2 > 0.f ? 1.f : -1.f;
+    job.use_edges = m >= 3 && fabsf(area2) > 1.0e-3f * extent * extent && extent > 0.f;
+    job.orient = area2 > 0.f ? 1.f : -1.f;
+    job.m = m;
+    job.slack = slack;
+    return true;
+}
+
+__device__ __forceinline__ bool cell_touched(const FaceJob& job, int res, int iu, int iv) {
+    if (!job.use_edges) return true;
     const float cw = 2.0f / (float)res;
-    const uint32_t id = (uint32_t)i;
-    for (int iv = iv0; iv <= iv1; ++iv) {
-        const float cv0 = -1.f + cw * (float)iv - slack, cv1 = -1.f + cw * (float)(iv + 1) + slack;
-        for (int iu = iu0; iu <= iu1; ++iu) {
-            bool touch = true;
-            if (use_edges) {
-                const float cu0 = -1.f + cw * (float)iu - slack, cu1 = -1.f + cw * (float)(iu + 1) + slack;
-                for (int q = 0; q < m && touch; ++q) {
-                    const int q2 = (q + 1) % m;
-                    // inward normal of edge q -> q2 for a counter-clockwise polygon: (-dy, dx)
-                    const float nx = -(pv[q2] - pv[q]) * orient, ny = (pu[q2] - pu[q]) * orient;
-                    // the cell corner farthest along the inward normal
-                    const float cx = nx > 0.f ? cu1 : cu0, cy = ny > 0.f ? cv1 : cv0;
-                    const float d = nx * (cx - pu[q]) + ny * (cy - pv[q]);
-                    const float len = fabsf(nx) + fabsf(ny);
-                    if (d < -1.0e-5f * len) touch = false;  // even that corner is outside this edge
-                }
-            }
-            if (!touch) continue;
-            const size_t cell = ((size_t)f * res + iv) * res + iu;
-            if (COUNT) atomicAdd(&cell_count[cell], 1u);
-            else list[cell_start[cell] + atomicAdd(&cell_count[cell], 1u)] = id;
+    const float cu0 = -1.f + cw * (float)iu - job.slack, cu1 = -1.f + cw * (float)(iu + 1) + job.slack;
+    const float cv0 = -1.f + cw * (float)iv - job.slack, cv1 = -1.f + cw * (float)(iv + 1) + job.slack;
+    for (int q = 0; q < job.m; ++q) {
+        const int q2 = (q + 1) % job.m;
+        // inward normal of edge q -> q2 for a counter-clockwise polygon: (-dy, dx)
+        const float nx = -(job.pv[q2] - job.pv[q]) * job.orient, ny = (job.pu[q2] - job.pu[q]) * job.orient;
+        // the cell corner farthest along the inward normal
+        const float cx = nx > 0.f ? cu1 : cu0, cy = ny > 0.f ? cv1 : cv0;
+        const float d = nx * (cx - job.pu[q]) + ny * (cy - job.pv[q]);
+        if (d < -1.0e-5f * (fabsf(nx) + fabsf(ny))) return false;  // even that corner is outside this edge
+    }
+    return true;
+}
+
+template <bool COUNT>
+__device__ __forceinline__ void enter(int res, int f, int iu, int iv, uint32_t id, uint32_t* __restrict__ cell_count,
+                                      const uint32_t* __restrict__ cell_start, uint32_t* __restrict__ list) {
+    const size_t cell = ((size_t)f * res + iv) * res + iu;
+    if (COUNT) atomicAdd(&cell_count[cell], 1u);
+    else list[cell_start[cell] + atomicAdd(&cell_count[cell], 1u)] = id;
+}
+
+constexpr int kInlineCells = 48;  // jobs covering more cells than this go to the queue of big jobs
+
+// One thread per (triangle, face). COUNT = true: cell_count[cell]++; false: list[cell_start[cell] + cursor[cell]++] = triangle.
+// A job whose bounding box covers many cells is not walked here but queued for grid_bin_big (one workgroup per job).
+template <bool COUNT>
+__global__ __launch_bounds__(128) void grid_bin_triangles(const float4* __restrict__ tris, int n, int res, uint32_t* __restrict__ cell_count,
+                                                          const uint32_t* __restrict__ cell_start, uint32_t* __restrict__ list,
+                                                          uint32_t* __restrict__ big_jobs, uint32_t* __restrict__ big_count, uint32_t big_capacity) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n * 6) return;
+    const int i = j / 6, f = j % 6;
+    FaceJob job;
+    if (!setup_job(tris, i, f, res, job)) return;
+    const int cells = (job.iu1 - job.iu0 + 1) * (job.iv1 - job.iv0 + 1);
+    if (cells > kInlineCells) {
+        const uint32_t slot = atomicAdd(big_count, 1u);
+        if (slot < big_capacity) {
+            big_jobs[slot] = (uint32_t)j;
+            return;
+        }
+        // queue full: walk it here after all
+    }
+    for (int iv = job.iv0; iv <= job.iv1; ++iv)
+        for (int iu = job.iu0; iu <= job.iu1; ++iu)
+            if (cell_touched(job, res, iu, iv)) enter<COUNT>(res, f, iu, iv, (uint32_t)i, cell_count, cell_start, list);
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) void grid_bin_big(const float4* __restrict__ tris, int res, uint32_t* __restrict__ cell_count,
+                                                    const uint32_t* __restrict__ cell_start, uint32_t* __restrict__ list,
+                                                    const uint32_t* __restrict__ big_jobs, const uint32_t* __restrict__ big_count, uint32_t big_capacity) {
+    const uint32_t queued = *big_count < big_capacity ? *big_count : big_capacity;
+    for (uint32_t slot = blockIdx.x; slot < queued; slot += gridDim.x) {
+        const int j = (int)big_jobs[slot], i = j / 6, f = j % 6;
+        FaceJob job;
+        if (!setup_job(tris, i, f, res, job)) continue;  // (cannot fail: it succeeded when the job was queued)
+        const int wu = job.iu1 - job.iu0 + 1, cells = wu * (job.iv1 - job.iv0 + 1);
+        for (int c = threadIdx.x; c < cells; c += blockDim.x) {
+            const int iu = job.iu0 + c % wu, iv = job.iv0 + c / wu;
+            if (cell_touched(job, res, iu, iv)) enter<COUNT>(res, f, iu, iv, (uint32_t)i, cell_count, cell_start, list);
         }
     }
+}
+
+template <bool COUNT>
+hipError_t bin_all(const PtGridBuild& g, const float* tris, int32_t n, hipStream_t stream) {
+    const size_t cells = (size_t)6 * g.res * g.res;
+    hipError_t e = hipMemsetAsync(g.cell_count, 0, (cells + 1) * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(g.big_count, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    const int jobs = n * 6;
+    const float4* t4 = reinterpret_cast<const float4*>(tris);
+    hipLaunchKernelGGL(grid_bin_triangles<COUNT>, dim3((jobs + 127) / 128), dim3(128), 0, stream, t4, n, g.res, g.cell_count, g.cell_start, g.list,
+                       g.big_jobs, g.big_count, g.big_capacity);
+    hipLaunchKernelGGL(grid_bin_big<COUNT>, dim3(2048), dim3(256), 0, stream, t4, g.res, g.cell_count, g.cell_start, g.list, g.big_jobs, g.big_count,
+                       g.big_capacity);
+    return hipGetLastError();
 }
 
 }  // namespace
@@ -153,11 +218,8 @@ size_t pt_grid_scan_temp_bytes(size_t cells) {
 
 hipError_t pt_grid_count(const PtGridBuild& g, const float* tris, int32_t n, hipStream_t stream) {
     const size_t cells = (size_t)6 * g.res * g.res;
-    hipError_t e = hipMemsetAsync(g.cell_count, 0, (cells + 1) * sizeof(uint32_t), stream);
+    hipError_t e = bin_all<true>(g, tris, n, stream);
     if (e != hipSuccess) return e;
-    const int jobs = n * 6;
-    hipLaunchKernelGGL(grid_bin_triangles<true>, dim3((jobs + 127) / 128), dim3(128), 0, stream, reinterpret_cast<const float4*>(tris), n, g.res,
-                       g.cell_count, (const uint32_t*)nullptr, (uint32_t*)nullptr);
     size_t bytes = g.scan_tmp_bytes;
     e = hipcub::DeviceScan::ExclusiveSum(g.scan_tmp, bytes, g.cell_count, g.cell_start, (int)(cells + 1), stream);
     if (e != hipSuccess) return e;
@@ -165,11 +227,5 @@ hipError_t pt_grid_count(const PtGridBuild& g, const float* tris, int32_t n, hip
 }
 
 hipError_t pt_grid_fill(const PtGridBuild& g, const float* tris, int32_t n, hipStream_t stream) {
-    const size_t cells = (size_t)6 * g.res * g.res;
-    hipError_t e = hipMemsetAsync(g.cell_count, 0, (cells + 1) * sizeof(uint32_t), stream);
-    if (e != hipSuccess) return e;
-    const int jobs = n * 6;
-    hipLaunchKernelGGL(grid_bin_triangles<false>, dim3((jobs + 127) / 128), dim3(128), 0, stream, reinterpret_cast<const float4*>(tris), n, g.res,
-                       g.cell_count, g.cell_start, g.list);
-    return hipGetLastError();
+    return bin_all<false>(g, tris, n, stream);
 }

@@ -79,6 +79,9 @@ struct PtGridBuild {
     size_t list_capacity;   // entries
     void* scan_tmp;
     size_t scan_tmp_bytes;
+    uint32_t* big_jobs;     // queue of (triangle, face) jobs that cover many cells: one workgroup each
+    uint32_t* big_count;    // 1
+    uint32_t big_capacity;
 };
 size_t pt_grid_scan_temp_bytes(size_t cells);
 // counts the entries of every cell and leaves their prefix sums in cell_start (read cell_start[cells] for the list length)

@@ -161,3 +161,52 @@ def test_million_triangle_scene_crops(tracer):
         assert_same(res)
         x0, y0, w, h = window
         assert (res["bvh"][0][y0:y0 + h, x0:x0 + w] >= 0).sum() > 100
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("res", [0, 32, 1024])
+def test_direction_grid_from_inside_a_cloud(seed, res):
+    """Camera in the middle of a random cloud: triangles on all six cube-map faces, across face edges and corners, some
+    huge, some almost touching the camera, some with an edge pointing straight at it, some seen at a grazing angle.
+    The grid (coarse, default and fine resolutions) must return what the all-triangles loop returns: ids, distances,
+    radiance with bounces in every direction."""
+    import os
+    from pathtracer_amd import Tracer, capi
+    rng = np.random.default_rng(100 + seed)
+    nt = 500
+    centre = rng.normal(size=(nt, 1, 3))
+    centre *= rng.uniform(0.05, 6.0, (nt, 1, 1)) / np.linalg.norm(centre, axis=2, keepdims=True)
+    tri = centre + rng.uniform(-1, 1, (nt, 3, 3)) * rng.choice([0.02, 0.3, 1.5, 8.0], (nt, 1, 1))
+    eye = np.array([0.1, -0.2, 0.05])
+    # edges pointing at the camera: C = A + s (A - eye)
+    for k in range(40):
+        tri[k, 2] = tri[k, 0] + rng.uniform(0.2, 2.0) * (tri[k, 0] - eye)
+    # grazing: third vertex almost in the plane through the camera and the first edge
+    for k in range(40, 80):
+        n = np.cross(tri[k, 0] - eye, tri[k, 1] - eye)
+        n /= np.linalg.norm(n)
+        mid = 0.5 * (tri[k, 0] + tri[k, 1])
+        tri[k, 2] = mid + (mid - eye) * 0.3 + n * rng.choice([1e-3, -1e-3, 1e-2]) * np.linalg.norm(mid - eye)
+    tri = tri.astype(np.float32)
+    verts = np.concatenate([tri.reshape(-1, 3), np.zeros((nt * 3, 3), np.float32)], axis=1).astype(np.float32)
+    idx = np.arange(nt * 3, dtype=np.uint32).reshape(-1, 3)
+    W, H = 160, 120
+    old = os.environ.get("PT_GRID_RES")
+    if res:
+        os.environ["PT_GRID_RES"] = str(res)
+    try:
+        t = Tracer(0)
+    finally:
+        if res:
+            if old is None:
+                del os.environ["PT_GRID_RES"]
+            else:
+                os.environ["PT_GRID_RES"] = old
+    try:
+        for target in [(1.0, 0.3, 0.2), (-0.2, -1.0, 0.4), (0.3, 0.2, -1.0)]:
+            cam = po.camera(100.0, W, H, eye, eye + np.array(target), (0.0, 1.0, 0.1))
+            res_ = both_modes(t, verts, idx, cam, W, H, 1, spp=4)
+            assert_same(res_)
+            assert (res_["brute"][0] >= 0).mean() > 0.5
+    finally:
+        t.close()
