@@ -243,13 +243,14 @@ def main():
                 "peak_unfused": PEAK_FP32_UNFUSED_TFLOPS,
                 "frac_unfused": achieved / PEAK_FP32_UNFUSED_TFLOPS,
                 "traffic": None,
-                "kernel": "pt_render_kernel<mesh>" if scene.program == 1 else "pt_render_kernel<world>",
+                "kernel": "pt_render_kernel<4,false> (direction grid)" if scene.program == 1 else "pt_render_kernel<0,false> (spheres)",
                 "kernel_ms": kernel_ms,
                 "algorithmic_flop_per_launch": flop_per_launch,
                 "note": "algorithmic flop = evaluated closest-hit queries x 43 x triangles, the shader's formulation (mul and add "
                         "counted separately; FMA is not permitted by the numerics contract); shading and RNG work is not counted. "
-                        "The kernel executes fewer: ray-independent terms are precomputed per triangle (25 flop per test), triangles "
-                        "the camera cannot see from the front are never visited, back-facing ones are skipped per wave.",
+                        "The kernel executes far fewer: a query tests only the triangles listed in the cube-map cell of its direction "
+                        "(1-2 on average), so this algorithmic rate can exceed the machine's peak; what the kernel is bound by is "
+                        "VALU issue of the shading arithmetic (valu_issue_busy, from the PMC profile).",
             },
         }
         if st["bvh_node_fetches"] > 0:
@@ -265,11 +266,12 @@ def main():
                                        "latency-bound pointer chasing served by L2/Infinity Cache, far below the HBM roof"}
         if large:
             out["large_scene"] = large
-        # HBM bytes per launch from rocprofv3 PMC passes of this same workload (profiles/r01_pmc_cornell_b.json: FETCH_SIZE
-        # 18304.6 KB doubled as the gfx950 correction prescribes, plus WRITE_SIZE 35437.5 KB); counters cannot be read
-        # from inside this run
+        # HBM bytes per launch from rocprofv3 PMC passes of this same workload (profiles/r01_pmc_cornell_grid.json:
+        # FETCH_SIZE 18270.9 KB doubled as the gfx950 correction prescribes, plus WRITE_SIZE 348350.6 KB, of which 33 MB are
+        # the image and the rest the parked samples of split tiles); counters cannot be read from inside this run
         if args.workload == "cornell" and (W, H, spp) == (1920, 1080, 256):
-            out["roofline"]["traffic"] = 37487744.0 + 36288000.0
+            out["roofline"]["traffic"] = 37418880.0 + 356711040.0
+            out["roofline"]["valu_issue_busy"] = 0.73
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, spp)
         print(json.dumps(out), flush=True)
