@@ -72,6 +72,7 @@ struct PtContext {
     float mesh_extent = 0.f;        // largest absolute vertex coordinate
     PtShadingMode shading_mode = PT_SHADE_REFERENCE;
     bool records_valid = false;
+    bool live_valid = false, bvh_emit_valid = false, grid_valid = false;  // derived from the records, refreshed on use
     float records_ro[3] = {0, 0, 0};
     // LBVH (optional)
     PtBvhBuild bvh{};
@@ -276,20 +277,40 @@ PtStatus ensure_records(PtContext* ctx) {
     if (ctx->records_valid && memcmp(ro, ctx->records_ro, sizeof ctx->records_ro) == 0) return PT_OK;
     PT_HIP_TRY(pt_launch_prepare_triangles(ctx->d_vertices, ctx->d_indices, ctx->num_triangles, ro, ctx->d_tris,
                                            ctx->d_vnormals, ctx->d_gnormals, ctx->d_cull, ctx->d_tris_abs, ctx->stream));
-    PT_HIP_TRY(pt_launch_compact_triangles(ctx->d_tris, ctx->num_triangles, ctx->d_tris_live, ctx->d_live_count, ctx->stream));
-    // the BVH's boxes and leaf-order records are expressed relative to the ray origin too
-    if (ctx->bvh_built) {
-        // absolute-box variant: its padding scales with the largest coordinate a ray origin or a box can have
-        ctx->bvh.scene_scale = std::max(ctx->mesh_extent, std::max(std::fabs(ro[0]), std::max(std::fabs(ro[1]), std::fabs(ro[2]))));
-        PT_HIP_TRY(pt_bvh_emit(ctx->bvh, ro, ctx->d_tris, ctx->d_tris_abs, ctx->stream));
-    }
-    if (ctx->grid_wanted) {
-        PtStatus gs = build_grid(ctx);
-        if (gs != PT_OK) return gs;
-    }
+    // what is derived from the records is brought up to date when a dispatch actually uses it (ensure_* below)
+    ctx->live_valid = false;
+    ctx->bvh_emit_valid = false;
+    ctx->grid_valid = false;
     memcpy(ctx->records_ro, ro, sizeof ctx->records_ro);
     ctx->records_valid = true;
     ctx->list_valid = false;  // new mesh or camera position: the tile costs will change
+    return PT_OK;
+}
+
+// compacted record array of the all-triangles loop
+PtStatus ensure_live(PtContext* ctx) {
+    if (ctx->live_valid) return PT_OK;
+    PT_HIP_TRY(pt_launch_compact_triangles(ctx->d_tris, ctx->num_triangles, ctx->d_tris_live, ctx->d_live_count, ctx->stream));
+    ctx->live_valid = true;
+    return PT_OK;
+}
+
+// the BVH's boxes and leaf-order records are expressed relative to the ray origin too
+PtStatus ensure_bvh_emit(PtContext* ctx) {
+    if (ctx->bvh_emit_valid || !ctx->bvh_built) return PT_OK;
+    const float* ro = ctx->records_ro;
+    // absolute-box variant: its padding scales with the largest coordinate a ray origin or a box can have
+    ctx->bvh.scene_scale = std::max(ctx->mesh_extent, std::max(std::fabs(ro[0]), std::max(std::fabs(ro[1]), std::fabs(ro[2]))));
+    PT_HIP_TRY(pt_bvh_emit(ctx->bvh, ro, ctx->d_tris, ctx->d_tris_abs, ctx->stream));
+    ctx->bvh_emit_valid = true;
+    return PT_OK;
+}
+
+PtStatus ensure_grid(PtContext* ctx) {
+    if (ctx->grid_valid || !ctx->grid_wanted) return PT_OK;
+    PtStatus s = build_grid(ctx);
+    if (s != PT_OK) return s;
+    ctx->grid_valid = true;  // (grid_built may still be false: lists too long for this scene)
     return PT_OK;
 }
 
@@ -338,10 +359,19 @@ PtStatus fill_params(PtContext* ctx, PtKernelParams* p, const Program** prog_out
         PT_REQUIRE(use_bvh || ctx->accel_mode != PT_ACCEL_BVH, PT_ERR_STATE, "the BVH covers all %d triangles but u_NumTriangles = %d",
                    ctx->num_triangles, u.num_triangles);
         p->shading_mode = (int32_t)ctx->shading_mode;
+        const bool grid_possible = ctx->grid_wanted && ctx->shading_mode == PT_SHADE_REFERENCE && u.num_triangles == ctx->num_triangles &&
+                                   u.num_triangles > 0 && (ctx->accel_mode == PT_ACCEL_GRID || (ctx->accel_mode == PT_ACCEL_AUTO && ctx->auto_grid));
+        if (grid_possible) {
+            PtStatus gs = ensure_grid(ctx);
+            if (gs != PT_OK) return gs;
+        }
         PT_REQUIRE(ctx->accel_mode != PT_ACCEL_GRID || (ctx->grid_built && ctx->shading_mode == PT_SHADE_REFERENCE && u.num_triangles == ctx->num_triangles),
                    PT_ERR_STATE, "PT_ACCEL_GRID needs pt_build_accel, PT_SHADE_REFERENCE and u_NumTriangles = all %d triangles", ctx->num_triangles);
-        const bool use_grid = ctx->grid_built && ctx->shading_mode == PT_SHADE_REFERENCE && u.num_triangles == ctx->num_triangles &&
-                              (ctx->accel_mode == PT_ACCEL_GRID || (ctx->accel_mode == PT_ACCEL_AUTO && ctx->auto_grid));  // measured faster at every size
+        const bool use_grid = grid_possible && ctx->grid_built;  // measured faster than loop and hierarchy at every size
+        if (use_bvh && !use_grid) {
+            PtStatus bs = ensure_bvh_emit(ctx);
+            if (bs != PT_OK) return bs;
+        }
         if (use_grid) {
             p->grid_start = ctx->grid.cell_start;
             p->grid_list = ctx->grid.list;
@@ -371,6 +401,11 @@ PtStatus fill_params(PtContext* ctx, PtKernelParams* p, const Program** prog_out
             p->cull = ctx->d_cull;
             p->tris = ctx->d_tris;
             p->live_count = nullptr;
+        }
+        // whatever kernel ends up walking the compacted array (the loop of the render or of the primary-hit kernel)
+        if (p->live_count && !p->grid_start && !p->bvh_nodes) {
+            PtStatus ls = ensure_live(ctx);
+            if (ls != PT_OK) return ls;
         }
     } else {
         PT_REQUIRE(ctx->have_spheres, PT_ERR_STATE, "no spheres uploaded: call pt_upload_spheres first");
