@@ -468,7 +468,7 @@ __device__ __forceinline__ Hit intersect_grid(const PtKernelParams& p, v3 rd, un
     int iu = (int)__builtin_floorf((fu * iw + 1.0f) * half), iv = (int)__builtin_floorf((fv * iw + 1.0f) * half);
     iu = iu < 0 ? 0 : (iu >= res ? res - 1 : iu);
     iv = iv < 0 ? 0 : (iv >= res ? res - 1 : iv);
-    const size_t cell = ((size_t)face * res + iv) * res + iu;
+    const uint32_t cell = ((uint32_t)face * (uint32_t)res + (uint32_t)iv) * (uint32_t)res + (uint32_t)iu;  // < 6 * 2048^2
     const uint32_t begin = p.grid_start[cell], end = p.grid_start[cell + 1];
     const float4* __restrict__ recs = reinterpret_cast<const float4*>(p.grid_tris);
     uint32_t next = begin < end ? p.grid_list[begin] : 0u;
