@@ -85,6 +85,7 @@ struct PtContext {
     bool grid_built = false;
     int32_t grid_res_override = 0;
     uint64_t grid_entries = 0;
+    unsigned long long* d_grid_estimate = nullptr;
 
     // target
     float* d_image[2] = {nullptr, nullptr};
@@ -214,7 +215,19 @@ int grid_resolution(const PtContext* ctx) {
 }
 
 PtStatus build_grid(PtContext* ctx) {
-    const int res = grid_resolution(ctx);
+    ctx->grid_built = false;
+    // Resolution: the preferred one, halved while the lists could exceed 2^30 entries (4 GiB) -- many triangles that each
+    // cover a large part of a fine grid. Below 32 cells per face edge the grid is given up; the other search modes remain.
+    if (!ctx->d_grid_estimate) PT_HIP_TRY(hipMalloc(&ctx->d_grid_estimate, sizeof(unsigned long long)));
+    int res = grid_resolution(ctx);
+    for (;; res /= 2) {
+        if (res < 32) return PT_OK;
+        unsigned long long bound = 0;
+        PT_HIP_TRY(pt_grid_estimate(ctx->d_tris, ctx->num_triangles, res, ctx->d_grid_estimate, ctx->stream));
+        PT_HIP_TRY(hipMemcpyAsync(&bound, ctx->d_grid_estimate, sizeof bound, hipMemcpyDeviceToHost, ctx->stream));
+        PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (bound < (1ull << 30)) break;
+    }
     PtGridBuild& g = ctx->grid;
     const size_t cells = (size_t)6 * res * res;
     if (g.res != res) {
@@ -228,14 +241,10 @@ PtStatus build_grid(PtContext* ctx) {
         PT_HIP_TRY(hipMalloc(&g.big_jobs, (size_t)g.big_capacity * sizeof(uint32_t)));
         PT_HIP_TRY(hipMalloc(&g.big_count, sizeof(uint32_t)));
     }
-    ctx->grid_built = false;
     PT_HIP_TRY(pt_grid_count(g, ctx->d_tris, ctx->num_triangles, ctx->stream));
     uint32_t total = 0;
     PT_HIP_TRY(hipMemcpyAsync(&total, g.cell_start + cells, sizeof total, hipMemcpyDeviceToHost, ctx->stream));
     PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    // a list that would not fit 2^31 entries (or 8 GiB) means triangles that each cover a large part of a very fine
-    // grid: leave the grid unbuilt, the other search modes still work
-    if ((uint64_t)total >= ((uint64_t)1 << 31)) return PT_OK;
     if ((size_t)total > g.list_capacity) {
         if (g.list) (void)hipFree(g.list);
         g.list = nullptr;
@@ -486,6 +495,7 @@ PtStatus pt_destroy(PtContext* ctx) {
     free_mesh(ctx);
     if (ctx->d_spheres) (void)hipFree(ctx->d_spheres);
     if (ctx->d_materials) (void)hipFree(ctx->d_materials);
+    if (ctx->d_grid_estimate) (void)hipFree(ctx->d_grid_estimate);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);

@@ -192,6 +192,24 @@ __global__ __launch_bounds__(256) void grid_bin_big(const float4* __restrict__ t
     }
 }
 
+// Upper bound of the list length at resolution `res`: the bounding-box cells of every job, summed in 64 bits.
+__global__ __launch_bounds__(256) void grid_estimate(const float4* __restrict__ tris, int n, int res, unsigned long long* __restrict__ total) {
+    __shared__ unsigned long long partial[4];
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long cells = 0;
+    if (j < n * 6) {
+        FaceJob job;
+        if (setup_job(tris, j / 6, j % 6, res, job)) cells = (unsigned long long)(job.iu1 - job.iu0 + 1) * (unsigned long long)(job.iv1 - job.iv0 + 1);
+    }
+    for (int off = 32; off > 0; off >>= 1) cells += __shfl_down(cells, off);
+    if ((threadIdx.x & 63) == 0) partial[threadIdx.x >> 6] = cells;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long sum = partial[0] + partial[1] + partial[2] + partial[3];
+        if (sum) atomicAdd(total, sum);
+    }
+}
+
 template <bool COUNT>
 hipError_t bin_all(const PtGridBuild& g, const float* tris, int32_t n, hipStream_t stream) {
     const size_t cells = (size_t)6 * g.res * g.res;
@@ -214,6 +232,14 @@ size_t pt_grid_scan_temp_bytes(size_t cells) {
     size_t bytes = 0;
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)(cells + 1), nullptr);
     return bytes;
+}
+
+hipError_t pt_grid_estimate(const float* tris, int32_t n, int res, unsigned long long* total, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(total, 0, sizeof(unsigned long long), stream);
+    if (e != hipSuccess) return e;
+    const int jobs = n * 6;
+    hipLaunchKernelGGL(grid_estimate, dim3((jobs + 255) / 256), dim3(256), 0, stream, reinterpret_cast<const float4*>(tris), n, res, total);
+    return hipGetLastError();
 }
 
 hipError_t pt_grid_count(const PtGridBuild& g, const float* tris, int32_t n, hipStream_t stream) {

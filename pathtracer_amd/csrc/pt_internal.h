@@ -84,6 +84,8 @@ struct PtGridBuild {
     uint32_t big_capacity;
 };
 size_t pt_grid_scan_temp_bytes(size_t cells);
+// *total <- an upper bound of the list length at resolution res (bounding-box cells of every triangle and face)
+hipError_t pt_grid_estimate(const float* tris, int32_t n, int res, unsigned long long* total, hipStream_t stream);
 // counts the entries of every cell and leaves their prefix sums in cell_start (read cell_start[cells] for the list length)
 hipError_t pt_grid_count(const PtGridBuild& g, const float* tris, int32_t n, hipStream_t stream);
 // fills list (capacity must cover cell_start[cells])

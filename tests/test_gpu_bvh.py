@@ -210,3 +210,55 @@ def test_direction_grid_from_inside_a_cloud(seed, res):
             assert (res_["brute"][0] >= 0).mean() > 0.5
     finally:
         t.close()
+
+
+def test_direction_grid_with_lists_that_would_not_fit():
+    """Thousands of triangles that each cover a large part of the sphere, on the finest grid: the lists would need billions
+    of entries, so the build coarsens the grid (or gives it up and PT_ACCEL_AUTO falls back). Either way the image equals
+    the all-triangles loop."""
+    import os
+    from pathtracer_amd import Tracer, capi
+    rng = np.random.default_rng(77)
+    nt = 3000
+    centre = rng.normal(size=(nt, 1, 3))
+    centre *= rng.uniform(0.5, 3.0, (nt, 1, 1)) / np.linalg.norm(centre, axis=2, keepdims=True)
+    tri = (centre + rng.uniform(-30, 30, (nt, 3, 3))).astype(np.float32)
+    verts = np.concatenate([tri.reshape(-1, 3), np.zeros((nt * 3, 3), np.float32)], axis=1).astype(np.float32)
+    idx = np.arange(nt * 3, dtype=np.uint32).reshape(-1, 3)
+    W, H = 96, 64
+    cam = po.camera(90.0, W, H, (0, 0, 0), (0.2, 0.1, 1.0), (0, 1, 0))
+    sph, _ = po.reference_spheres_and_materials()
+    old = os.environ.get("PT_GRID_RES")
+    os.environ["PT_GRID_RES"] = "2048"
+    try:
+        t = Tracer(0)
+    finally:
+        if old is None:
+            del os.environ["PT_GRID_RES"]
+        else:
+            os.environ["PT_GRID_RES"] = old
+    try:
+        prog = t.program_create(capi.PROGRAM_MESH)
+        t.use_program(prog)
+        t.upload_spheres(sph)
+        t.upload_mesh(verts, idx)
+        t.set_normal_mode(1)
+        t.target_create(W, H)
+        t.set_uniforms(cam, nt, 10)
+        t.build_accel()
+        out = {}
+        for name, mode in (("auto", capi.ACCEL_AUTO), ("brute", capi.ACCEL_BRUTE)):
+            t.set_accel_mode(mode)
+            t.target_clear()
+            ids, ts = t.readback_primary()
+            t.dispatch(1, 3, 1)
+            t.finish()
+            out[name] = (ids, ts, t.readback())
+        st = t.stats()
+        assert st["grid_entries"] < (1 << 30)
+        assert np.array_equal(out["auto"][0], out["brute"][0])
+        assert n_bit_mismatch(out["auto"][1], out["brute"][1]) == 0
+        assert n_bit_mismatch(out["auto"][2], out["brute"][2]) == 0
+        assert (out["brute"][0] >= 0).mean() > 0.9
+    finally:
+        t.close()
