@@ -163,6 +163,35 @@ def test_million_triangle_scene_crops(tracer):
         assert (res["bvh"][0][y0:y0 + h, x0:x0 + w] >= 0).sum() > 100
 
 
+@pytest.mark.parametrize("workload,size,spp", [("instanced", (1920, 1080), 8), ("cornell", (960, 540), 32), ("suzanne", (640, 360), 48)])
+def test_direction_grid_equals_hierarchy_on_full_frames(tracer, workload, size, spp):
+    """Full frames, tens of millions of closest-hit queries in every direction a bounce can take: the direction grid
+    against the LBVH (itself pinned to the all-triangles loop above): ids, distances, radiance, ray counts."""
+    from pathtracer_amd import capi
+    from pathtracer_amd.scenes import SceneData
+    sc = SceneData(workload, *size)
+    t = tracer
+    prog = sc.upload(t)
+    t.set_accum_mode(capi.ACCUM_MEAN)
+    t.target_create(sc.width, sc.height)
+    out = {}
+    for name, mode in (("bvh", capi.ACCEL_BVH), ("grid", capi.ACCEL_GRID)):
+        t.set_accel_mode(mode)
+        t.target_clear()
+        t.reset_stats()
+        ids, ts = t.readback_primary()
+        t.dispatch(1, spp, 1)
+        t.finish()
+        st = t.stats()
+        out[name] = (ids, ts, t.readback(), st["rays"])
+    assert out["grid"][3] == out["bvh"][3] and st["rays_traced"] > 1_000_000
+    assert np.array_equal(out["grid"][0], out["bvh"][0])
+    assert n_bit_mismatch(out["grid"][1], out["bvh"][1]) == 0
+    assert n_bit_mismatch(out["grid"][2], out["bvh"][2]) == 0
+    t.set_accel_mode(capi.ACCEL_AUTO)
+    t.program_destroy(prog)
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 @pytest.mark.parametrize("res", [0, 32, 1024])
 def test_direction_grid_from_inside_a_cloud(seed, res):
