@@ -137,7 +137,7 @@ struct PthRenderOptions {
     const char* output_tga;    // may be NULL
     int width, height, passes, samples_per_dispatch, program_kind, device, depth;
     int shade_materials;       // 1 = PT_SHADE_MATERIALS with the MTL-derived table
-    int accel;                 // 1 = build the LBVH
+    int accel;                 // 1 = pt_build_accel (direction grid / LBVH), 0 = the shader's plain loop
     int custom_camera;         // 1 = use eye/target/up/fov below instead of the reference's camera
     float eye[3], target[3], up[3], fov;
     float translate_z;

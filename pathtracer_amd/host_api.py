@@ -134,9 +134,9 @@ def shader_stage_for_file(filename):
 
 
 def render(obj_path, width, height, passes, samples_per_dispatch=1, program_kind=1, device=0, mtl_basedir=None, output_tga=None,
-           shading="reference", accel="loop", camera_eye_target_fov=None, translate_z=3.0, depth=10):
+           shading="reference", accel="auto", camera_eye_target_fov=None, translate_z=3.0, depth=10):
     """Runs the C++ render loop; returns (accumulationBuffer [h,w,3] running sum, colorBuffer [h,w,4] uint8, stats).
-    shading "materials" = PT_SHADE_MATERIALS with the table built from the OBJ's MTL file; accel "bvh" builds the LBVH;
+    shading "materials" = PT_SHADE_MATERIALS with the table built from the OBJ's MTL file; accel "loop" keeps the shader's all-triangles loop instead of the direction grid / LBVH;
     camera_eye_target_fov = (eye xyz, target xyz, fov degrees) replaces the reference's fixed camera."""
     rgb = np.zeros((height, width, 3), np.float32)
     rgba8 = np.zeros((height, width, 4), np.uint8)
@@ -149,7 +149,7 @@ def render(obj_path, width, height, passes, samples_per_dispatch=1, program_kind
     o.width, o.height, o.passes, o.samples_per_dispatch = width, height, passes, samples_per_dispatch
     o.program_kind, o.device, o.depth = program_kind, device, depth
     o.shade_materials = 1 if shading == "materials" else 0
-    o.accel = 1 if accel == "bvh" else 0
+    o.accel = 0 if accel == "loop" else 1
     o.translate_z = translate_z
     o.up[:] = (0.0, 1.0, 0.0)
     o.target[:] = (0.0, 0.0, 1.0)

@@ -376,7 +376,7 @@ def test_cpp_host_render_loop(tmp_path):
     assert n_bit_mismatch(rgb_sum2, rgb_sum) == 0
 
 
-@pytest.mark.parametrize("accel", ["loop", "bvh"])
+@pytest.mark.parametrize("accel", ["loop", "auto"])
 def test_cpp_host_materials_mode(accel):
     """C++ host end to end in the diffuse/emissive mode: OBJ + MTL -> material table and per-triangle ids -> 16 frames;
     the Framebuffer must hold the llvmpipe golden of the Cornell box."""
