@@ -66,8 +66,8 @@ def trace(msg):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cornell")
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
