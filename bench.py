@@ -74,7 +74,11 @@ def main():
     ap.add_argument("--spp", type=int, default=256, help="samples per pixel per step and per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-second-scene", action="store_true", help="skip the short 1M-triangle run reported under 'large_scene'")
+    ap.add_argument("--lean", action="store_true", help="warm-up and timed steps only (no CPU baseline, no 1M-triangle run, no "
+                    "no-reuse comparison): what to put behind rocprofv3 so that the kernel statistics cover exactly these launches")
     args = ap.parse_args()
+    if args.lean:
+        args.no_cpu_baseline = args.no_second_scene = True
 
     import torch
     import torch.distributed as dist
@@ -149,18 +153,20 @@ def main():
     st = tracer.stats()
 
     # the same steps with the camera ray evaluated for every sample, as the shader does (outside the timed region, for the record)
-    tracer.set_primary_reuse(False)
-    for _ in range(2):
-        step()
-    fence()
-    tracer.reset_stats()
-    t1 = time.perf_counter()
-    for _ in range(3):
-        step()
-    fence()
-    plain_elapsed = (time.perf_counter() - t1) / 3
-    plain = tracer.stats()
-    tracer.set_primary_reuse(True)
+    plain, plain_elapsed = None, 0.0
+    if not args.lean:
+        tracer.set_primary_reuse(False)
+        for _ in range(2):
+            step()
+        fence()
+        tracer.reset_stats()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            step()
+        fence()
+        plain_elapsed = (time.perf_counter() - t1) / 3
+        plain = tracer.stats()
+        tracer.set_primary_reuse(True)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     counts = torch.tensor([float(st["rays"]), float(st["samples"])], dtype=torch.float64, device=device)
@@ -230,7 +236,8 @@ def main():
                                "'rays_traced_per_s' counts only evaluated queries; 'no_primary_reuse' is the same step without the reuse.",
             "primary_reuse": True,
             "rays_traced_per_s": st["rays_traced"] * world / elapsed if world == 1 else None,
-            "no_primary_reuse": {"value": plain["rays"] / 3 / plain_elapsed * 1e-6 * world, "unit": "Mrays/s", "ms_per_step": plain_elapsed * 1e3,
+            "no_primary_reuse": None if plain is None else
+                                {"value": plain["rays"] / 3 / plain_elapsed * 1e-6 * world, "unit": "Mrays/s", "ms_per_step": plain_elapsed * 1e3,
                                  "kernel_ms": plain["total_dispatch_ms"] / max(1, plain["dispatches"]), "note": "rank 0 clock, 3 steps after 2 warm-up steps"},
             "samples_per_s": samples / elapsed,
             "rays_per_sample": rays / samples if samples else 0.0,
