@@ -59,13 +59,14 @@ int RunRenderLoop(const RenderOptions& opt, Framebuffer& fb, RenderResult& resul
         return 1;
     }
     std::vector<ptobj::material_t> materials;
-    if (opt.translate_z != 3.f || opt.custom_camera || opt.shade_materials) {
+    if (opt.translate_z != 3.f || opt.custom_camera || opt.shade_materials || opt.file_normals) {
         // non-reference framing or shading: rebuild mesh / camera with the requested values, keep the MTL data
         ptobj::attrib_t attrib;
         std::vector<ptobj::shape_t> shapes;
         ptobj::LoadObj(&attrib, &shapes, &materials, &err, opt.obj_path.c_str(),
                        opt.mtl_basedir.empty() ? nullptr : opt.mtl_basedir.c_str());
-        scene.meshes[0] = buildMesh(attrib, shapes, 1.0f, float3(0.f, 0.f, opt.translate_z));
+        scene.meshes[0] = opt.file_normals ? buildMeshIndexedNormals(attrib, shapes, 1.0f, float3(0.f, 0.f, opt.translate_z))
+                                           : buildMesh(attrib, shapes, 1.0f, float3(0.f, 0.f, opt.translate_z));
         if (opt.custom_camera) {
             scene.camera.initialize(opt.fov, 0.1f, 100.f, (float)width, (float)height);
             scene.camera.lookAt(float3(opt.eye[0], opt.eye[1], opt.eye[2]), float3(opt.target[0], opt.target[1], opt.target[2]),

@@ -1,5 +1,9 @@
 #include "Scene.h"
 
+#include <algorithm>
+#include <map>
+#include <utility>
+
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>
@@ -96,6 +100,43 @@ void buildReferenceSpheres(Scene& scene) {
         mt.type = (float)id;
         scene.materials.push_back(mt);
     }
+}
+
+Mesh buildMeshIndexedNormals(const ptobj::attrib_t& attrib, const std::vector<ptobj::shape_t>& shapes, float scale,
+                             const float3& translation) {
+    Mesh m;
+    m.bounds_min = float3(3.0e38f);
+    m.bounds_max = float3(-3.0e38f);
+    m.has_vertex_normals = true;
+    std::map<std::pair<int, int>, int> seen;
+    const size_t num_normals = attrib.normals.size() / 3, num_positions = attrib.vertices.size() / 3;
+    for (const ptobj::shape_t& s : shapes) {
+        for (size_t k = 0; k < s.mesh.indices.size(); ++k) {
+            const ptobj::index_t& ix = s.mesh.indices[k];
+            const bool has_normal = ix.normal_index >= 0 && (size_t)ix.normal_index < num_normals;
+            if (!has_normal) m.has_vertex_normals = false;
+            const std::pair<int, int> key(ix.vertex_index, has_normal ? ix.normal_index : -1);
+            auto it = seen.find(key);
+            if (it == seen.end()) {
+                Vertex v;
+                if (ix.vertex_index >= 0 && (size_t)ix.vertex_index < num_positions) {
+                    const float* p = &attrib.vertices[3 * (size_t)ix.vertex_index];
+                    v.position = float3(p[0] * scale, p[1] * scale, p[2] * scale + translation.z);  // same rule as buildMesh
+                }
+                if (has_normal) {
+                    const float* n = &attrib.normals[3 * (size_t)ix.normal_index];
+                    v.normal = float3(n[0], n[1], n[2]);
+                }
+                m.bounds_min = float3(std::min(m.bounds_min.x, v.position.x), std::min(m.bounds_min.y, v.position.y), std::min(m.bounds_min.z, v.position.z));
+                m.bounds_max = float3(std::max(m.bounds_max.x, v.position.x), std::max(m.bounds_max.y, v.position.y), std::max(m.bounds_max.z, v.position.z));
+                it = seen.emplace(key, (int)m.vertices.size()).first;
+                m.vertices.push_back(v);
+            }
+            m.indices.push_back(it->second);
+            if (k % 3 == 0) m.material_ids.push_back(k / 3 < s.mesh.material_ids.size() ? s.mesh.material_ids[k / 3] : -1);
+        }
+    }
+    return m;
 }
 
 std::vector<Material> buildMaterialTable(const std::vector<ptobj::material_t>& mtl, const float3& unassigned) {

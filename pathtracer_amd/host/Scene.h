@@ -81,6 +81,14 @@ struct Scene {
 Mesh buildMesh(const ptobj::attrib_t& attrib, const std::vector<ptobj::shape_t>& shapes, float scale = 1.0f,
                const float3& translation = float3(0.0f, 0.0f, 3.f));
 
+// The same mesh with the normals the OBJ file actually assigns: every corner takes attrib.normals[normal_index] (the
+// reference takes attrib.normals[vertex_index], which is only right for files whose `vn` lines run parallel to their `v`
+// lines). Vertices are the distinct (vertex_index, normal_index) pairs in order of first use, so triangle order -- and
+// with it every triangle id -- is unchanged. Corners without a normal index get a zero normal; has_vertex_normals is
+// true only when every corner has one.
+Mesh buildMeshIndexedNormals(const ptobj::attrib_t& attrib, const std::vector<ptobj::shape_t>& shapes, float scale = 1.0f,
+                             const float3& translation = float3(0.0f, 0.0f, 3.f));
+
 // Table for the diffuse/emissive shading mode (PT_SHADE_MATERIALS), one row per MTL material plus a last row for
 // triangles without `usemtl`. The reference parses MTL files (tiny_obj_loader.h:956-1324) and never looks at the result,
 // so the rule is this build's: emission = Ke, or Ka when Ke is zero and a Ka component exceeds 1 (cornell_box.mtl marks

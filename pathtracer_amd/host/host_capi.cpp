@@ -101,6 +101,18 @@ PTH_API int pth_obj_build_mesh(const PthObj* o, float scale, float translate_z, 
     return m.has_vertex_normals ? 1 : 0;
 }
 
+// The mesh with the normals the file assigns (normal_index): call with NULL arrays for the vertex count, then again to copy.
+// Triangle order equals pth_obj_build_mesh's. Returns the vertex count; *has_normals = every corner carries a normal index.
+PTH_API int pth_obj_build_mesh_indexed_normals(const PthObj* o, float scale, float translate_z, float* vertices6, unsigned* indices,
+                                               int* has_normals) {
+    pthost::Mesh m = pthost::buildMeshIndexedNormals(o->attrib, o->shapes, scale, pthost::float3(0.f, 0.f, translate_z));
+    if (vertices6 && !m.vertices.empty()) memcpy(vertices6, m.vertices.data(), m.vertices.size() * sizeof(pthost::Vertex));
+    if (indices)
+        for (size_t i = 0; i < m.indices.size(); ++i) indices[i] = (unsigned)m.indices[i];
+    if (has_normals) *has_normals = m.has_vertex_normals ? 1 : 0;
+    return (int)m.vertices.size();
+}
+
 // out12 = position, lowerLeftCorner, horizontal, vertical
 PTH_API void pth_camera(float fov, float width, float height, const float* eye, const float* target, const float* up, float* out12) {
     pthost::Camera c;

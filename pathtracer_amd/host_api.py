@@ -35,6 +35,8 @@ def load():
         L.pth_obj_material_table.argtypes = [C.c_void_p, C.c_void_p]
         L.pth_render_ex.restype = C.c_int
         L.pth_render_ex.argtypes = [C.POINTER(PthRenderOptions), C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
+        L.pth_obj_build_mesh_indexed_normals.restype = C.c_int
+        L.pth_obj_build_mesh_indexed_normals.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         L.pth_obj_build_mesh.restype = C.c_int
         L.pth_obj_build_mesh.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         L.pth_camera.argtypes = [C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -93,6 +95,12 @@ class ObjFile:
             self._build = lambda scale, tz: self._build_mesh(L, h, scale, tz)
             self.mesh_default = self._build_mesh(L, h, 1.0, 3.0)
             self.mesh_untranslated = self._build_mesh(L, h, 1.0, 0.0)
+            # the same triangles with the normals the file assigns through its normal indices
+            has_n = C.c_int(0)
+            nvx = L.pth_obj_build_mesh_indexed_normals(h, 1.0, 3.0, None, None, C.byref(has_n))
+            vx, ix = np.zeros((nvx, 6), np.float32), np.zeros((nt, 3), np.uint32)
+            L.pth_obj_build_mesh_indexed_normals(h, 1.0, 3.0, vx.ctypes.data, ix.ctypes.data, C.byref(has_n))
+            self.mesh_indexed_normals = {"vertices": vx, "indices": ix, "has_vertex_normals": bool(has_n.value)}
         finally:
             L.pth_obj_free(h)
 

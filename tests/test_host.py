@@ -125,6 +125,28 @@ def test_mesh_build_matches_reference_rule():
     assert c.mesh_default["material_ids"].tolist()[:8] == [0, 0, 0, 0, 0, 0, 4, 4]
 
 
+def test_mesh_with_the_files_own_normal_indices():
+    """monkeyhead2.obj has 507 positions and 529 normals: the reference pairs normal k with position k, the file pairs
+    them through normal_index. The second builder must give the same triangles (same positions, same order) with the
+    file's normals on every corner."""
+    ref = np.load(f"{GOLDEN}/obj_monkeyhead2.npz")
+    o = host.ObjFile(f"{A}/monkeyhead2.obj", A + "/")
+    plain, fixed = o.mesh_default, o.mesh_indexed_normals
+    assert fixed["has_vertex_normals"] and len(fixed["indices"]) == len(plain["indices"]) == 968
+    assert len(fixed["vertices"]) >= 529
+    pos_plain = plain["vertices"][plain["indices"].reshape(-1)][:, :3]
+    pos_fixed = fixed["vertices"][fixed["indices"].reshape(-1)][:, :3]
+    assert n_bit_mismatch(pos_plain, pos_fixed) == 0
+    nrm_fixed = fixed["vertices"][fixed["indices"].reshape(-1)][:, 3:]
+    assert n_bit_mismatch(nrm_fixed, ref["vn"][ref["idx_vn"].reshape(-1)]) == 0
+    # and it differs from the reference's pairing somewhere, otherwise the option would be pointless for this file
+    nrm_plain = plain["vertices"][plain["indices"].reshape(-1)][:, 3:]
+    assert n_bit_mismatch(nrm_plain, nrm_fixed) > 0
+    # files without normals: every corner gets a zero normal, geometric normals are to be used
+    c = host.ObjFile(f"{A}/cornell_box.obj", A + "/")
+    assert not c.mesh_indexed_normals["has_vertex_normals"] and np.all(c.mesh_indexed_normals["vertices"][:, 3:] == 0)
+
+
 def test_camera_and_spheres_match_oracle_restatement():
     for (fov, w, h, eye, tgt, up) in [(60.0, 1280, 720, (0, 0, 0), (0, 0, 1), (0, 1, 0)),
                                       (39.3, 1920, 1080, (278, 273, -800), (278, 273, 0), (0, 1, 0)),
