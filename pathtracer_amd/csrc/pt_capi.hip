@@ -107,6 +107,7 @@ struct PtContext {
     int32_t wave_slots = 0;               // waves the device holds at once (CUs x 4 SIMDs x 8)
     float split_factor = -1.f;            // < 0: chosen per kernel family, see pt_dispatch
     bool primary_reuse = true;
+    bool lane_walk = true;                // PT_LANE_WALK=0: materials mode walks the hierarchy once per wave, not per lane
     bool auto_grid = true;                // PT_AUTO_GRID=0: PT_ACCEL_AUTO never picks the direction grid (for comparisons)
     bool keep_unreachable = false;        // PT_KEEP_UNREACHABLE=1: the loop walks all records (to measure the compaction)
     int32_t sched_win[4] = {-1, -1, -1, -1};  // window the costs were measured for
@@ -398,6 +399,7 @@ PtStatus fill_params(PtContext* ctx, PtKernelParams* p, const Program** prog_out
             p->materials = ctx->d_materials;
             p->material_ids = ctx->d_material_ids;
             if (use_bvh) {
+                p->lane_walk = ctx->lane_walk ? 1 : 0;
                 p->bvh_nodes_abs = ctx->bvh.nodes_abs;
                 p->bvh_tris_abs = ctx->bvh.sorted_tris_abs;
                 p->bvh_ids = ctx->bvh.sorted_ids;
@@ -481,6 +483,7 @@ PtStatus pt_create(int32_t device, PtContext** out_ctx) {
     ctx->wave_slots = prop.multiProcessorCount * 4 * 8;
     if (const char* g = getenv("PT_AUTO_GRID")) ctx->auto_grid = g[0] != '0';
     if (const char* g = getenv("PT_GRID_RES")) ctx->grid_res_override = atoi(g);
+    if (const char* l = getenv("PT_LANE_WALK")) ctx->lane_walk = l[0] != '0';
     if (const char* k = getenv("PT_KEEP_UNREACHABLE")) ctx->keep_unreachable = k[0] == '1';
     if (const char* f = getenv("PT_SPLIT_FACTOR")) ctx->split_factor = (float)atof(f);  // for experiments
     *out_ctx = ctx;
@@ -689,6 +692,7 @@ PtStatus pt_build_accel(PtContext* ctx) {
         free_bvh(ctx);
         return fail(PT_ERR_HIP, "BVH build failed: %s", hipGetErrorString(e));
     }
+    if (getenv("PT_DEBUG_SCHED")) fprintf(stderr, "[pt bvh] %d triangles, hierarchy finished after %d bottom-up sweeps\n", n, ctx->bvh_refit_passes);
     ctx->bvh_built = true;
     ctx->records_valid = false;  // leaf-order records and origin-relative boxes are emitted with the next records
     return PT_OK;

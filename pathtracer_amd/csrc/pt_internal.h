@@ -150,6 +150,7 @@ struct PtKernelParams {
     const float* bvh_tris;              // triangle records in leaf order
     const int32_t* bvh_ids;             // triangle id of each leaf-order record
     const float* bvh_nodes_abs;         // LBVH records with absolute boxes (rays with their own origin)
+    int32_t lane_walk;                  // 1: one hierarchy walk per lane (incoherent rays) instead of one per wave
     const float* bvh_tris_abs;          // a, e1, e2 records in leaf order
     const float* spheres;               // 10 x (cx, cy, cz, r)
     const float* src;                   // RGBA32F image read (previous result)

@@ -449,6 +449,91 @@ __device__ __forceinline__ Hit intersect_bvh(const PtKernelParams& p, v3 ro, v3 
     return h;
 }
 
+// Closest hit through the LBVH with one traversal per LANE, for rays that have little in common (diffuse bounces from
+// scattered hit points): every lane keeps its own stack (LDS, PT_LANE_STACK entries, lane-interleaved) and fetches its own
+// node and triangle records with vector loads, so a lane only visits what its own ray needs instead of the union over
+// the wave. Same padded boxes, same slab arithmetic, same exact triangle test with the explicit lowest-id rule as the
+// per-wave walk. A lane whose stack would overflow (very deep hierarchy) reports it; the caller repeats that lane's query
+// with the per-wave walk, which has room for any hierarchy.
+#define PT_LANE_STACK 24
+__device__ __forceinline__ Hit intersect_bvh_lanes(const PtKernelParams& p, v3 ro, v3 rd, uint32_t* __restrict__ lstack, bool& overflow,
+                                                   unsigned& steps) {
+    Hit h;
+    h.t = 1.0e38f; h.id = -1; h.u = 0.f; h.v = 0.f; h.ood = 0.f;
+    overflow = false;
+    const float tiny = 1.0e-20f;
+    const float ix = __builtin_amdgcn_rcpf(__builtin_fabsf(rd.x) > tiny ? rd.x : __builtin_copysignf(tiny, rd.x));
+    const float iy = __builtin_amdgcn_rcpf(__builtin_fabsf(rd.y) > tiny ? rd.y : __builtin_copysignf(tiny, rd.y));
+    const float iz = __builtin_amdgcn_rcpf(__builtin_fabsf(rd.z) > tiny ? rd.z : __builtin_copysignf(tiny, rd.z));
+    const float ax = __builtin_fabsf(ix), ay = __builtin_fabsf(iy), az = __builtin_fabsf(iz);
+    const float ox = ro.x * ix, oy = ro.y * iy, oz = ro.z * iz;
+    const float4* __restrict__ nodes = reinterpret_cast<const float4*>(p.bvh_nodes_abs);
+    const float4* __restrict__ recs = reinterpret_cast<const float4*>(p.bvh_tris_abs);
+    uint32_t* __restrict__ my = lstack + (threadIdx.x & 63);
+    uint32_t ref = 0;  // root = internal node 0
+    int sp = 0;
+    for (;;) {
+        // descend until this lane holds a leaf (or ran out of nodes)
+        while (!(ref & 0x80000000u)) {
+            ++steps;
+            const float4 n0 = nodes[4 * (size_t)ref], n1 = nodes[4 * (size_t)ref + 1], n2 = nodes[4 * (size_t)ref + 2], n3 = nodes[4 * (size_t)ref + 3];
+            const float limit = h.t * 1.0001f;
+            float m, t;
+            m = n0.w * ax; t = __builtin_fmaf(n0.x, ix, -ox); float lnear = t - m, lfar = t + m;
+            m = n1.x * ay; t = __builtin_fmaf(n0.y, iy, -oy); const float lny = t - m, lfy = t + m;
+            m = n1.y * az; t = __builtin_fmaf(n0.z, iz, -oz); const float lnz = t - m, lfz = t + m;
+            lnear = __builtin_fmaxf(__builtin_fmaxf(lnear, lny), __builtin_fmaxf(lnz, 0.0f));
+            lfar = __builtin_fminf(__builtin_fminf(lfar, lfy), __builtin_fminf(lfz, limit));
+            m = n2.y * ax; t = __builtin_fmaf(n1.z, ix, -ox); float rnear = t - m, rfar = t + m;
+            m = n2.z * ay; t = __builtin_fmaf(n1.w, iy, -oy); const float rny = t - m, rfy = t + m;
+            m = n2.w * az; t = __builtin_fmaf(n2.x, iz, -oz); const float rnz = t - m, rfz = t + m;
+            rnear = __builtin_fmaxf(__builtin_fmaxf(rnear, rny), __builtin_fmaxf(rnz, 0.0f));
+            rfar = __builtin_fminf(__builtin_fminf(rfar, rfy), __builtin_fminf(rfz, limit));
+            const bool hl = lnear <= lfar, hr = rnear <= rfar;
+            const uint32_t lref = __float_as_uint(n3.x), rref = __float_as_uint(n3.y);
+            if (hl && hr) {
+                const bool left_first = lnear <= rnear;
+                if (sp >= PT_LANE_STACK) { overflow = true; return h; }
+                my[sp * 64] = left_first ? rref : lref;
+                ++sp;
+                ref = left_first ? lref : rref;
+            } else if (hl || hr) {
+                ref = hl ? lref : rref;
+            } else {
+                if (sp == 0) return h;
+                --sp;
+                ref = my[sp * 64];
+            }
+        }
+        // leaf: up to PT_BVH_LEAF_MAX consecutive records
+        const int first = (int)((ref & 0x7fffffffu) >> 3), count = (int)(ref & 7u) + 1;
+        for (int k = 0; k < count; ++k) {
+            ++steps;
+            const float4 ra = recs[4 * (size_t)(first + k)], rb = recs[4 * (size_t)(first + k) + 1], rc = recs[4 * (size_t)(first + k) + 2],
+                         rdd = recs[4 * (size_t)(first + k) + 3];
+            // fs:136-168 as written: record = a.xyz e1.x | e1.yz e2.xy | e2.z - - - | - - - id
+            const v3 a = V(ra.x, ra.y, ra.z), e1 = V(ra.w, rb.x, rb.y), e2 = V(rb.z, rb.w, rc.x);
+            const v3 q = cross3(rd, e2);
+            const float det = dot3(e1, q);
+            const v3 ap = ro - a;
+            const v3 r = cross3(ap, e1);
+            const float u = dot3(ap, q);
+            const float v = dot3(rd, r);
+            if ((det >= 0.0001f) & (u >= 0.0f) & (v >= 0.0f) & ((u + v) <= det)) {
+                const float ood = 1.0f / det;
+                const float tt = dot3(e2, r) * ood;
+                const int id = (int)__float_as_uint(rdd.w);
+                if (tt > 0.0f && (tt < h.t || (tt == h.t && id < h.id))) {
+                    h.t = tt; h.id = id; h.u = u; h.v = v; h.ood = ood;
+                }
+            }
+        }
+        if (sp == 0) return h;
+        --sp;
+        ref = my[sp * 64];
+    }
+}
+
 // Direction-grid query (see pt_grid.hip): the cell of the ray's direction lists the triangles it can hit at all. Every
 // lane walks its own list (lanes of a wave look in different cells), records come through per-lane vector loads; the
 // index of the next entry is fetched while the current triangle is tested. Same exact test, explicit lowest-index rule.
@@ -630,7 +715,8 @@ __device__ __forceinline__ unsigned __reduce_max_trips(unsigned v) {
 // radiance, origin moves to each hit point, so the ray-origin-specific triangle records cannot be used).
 template <int KIND, bool MATERIALS>
 __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKernelParams p) {
-    __shared__ uint32_t s_stack[KIND == 2 ? PT_TILE_WAVES : 1][KIND == 2 ? PT_BVH_STACK : 1];
+    __shared__ uint32_t s_stack[(KIND == 2 || KIND == 5) ? PT_TILE_WAVES : 1][(KIND == 2 || KIND == 5) ? PT_BVH_STACK : 1];
+    __shared__ uint32_t s_lane_stack[KIND == 5 ? PT_TILE_WAVES : 1][KIND == 5 ? PT_LANE_STACK * 64 : 1];
     // Which tile and which of its samples this block renders. Blocks start in blockIdx order and the work list is sorted
     // most expensive first, so the long items do not start last; a tile that would be a long serial chain of samples on
     // one wave is split over several blocks (their samples are folded in order afterwards). Any list that covers every
@@ -680,6 +766,11 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
             if (KIND == 0) h = intersect_world(p.spheres, o, d, n);
             else if (KIND == 1) h = MATERIALS ? intersect_mesh_from(p.tris_abs, p.num_triangles, o, d) : intersect_mesh(p.tris, live_triangles(p), d);
             else if (KIND == 2) h = intersect_bvh<MATERIALS>(p, o, d, s_stack[threadIdx.x >> 6], node_visits, tri_tests);
+            else if (KIND == 5) {
+                bool overflow;
+                h = intersect_bvh_lanes(p, o, d, s_lane_stack[threadIdx.x >> 6], overflow, lane_tests);
+                if (overflow) h = intersect_bvh<true>(p, o, d, s_stack[threadIdx.x >> 6], node_visits, tri_tests);
+            }
             else h = intersect_grid(p, d, lane_tests);
         }
         const bool hit = want && h.id >= 0;
@@ -779,7 +870,7 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
         reinterpret_cast<float4*>(p.dst)[pix] = make_float4(mr, mg, mb, alpha);
     }
     const unsigned long long wave_rays = wave_sum(rays), wave_traced = wave_sum(traced);
-    const unsigned long long wave_tests = KIND == 4 ? wave_sum(lane_tests) : 0ull;
+    const unsigned long long wave_tests = (KIND == 4 || KIND == 5) ? wave_sum(lane_tests) : 0ull;
     const unsigned wave_trips = __builtin_amdgcn_readfirstlane(__reduce_max_trips(trips));
     if ((threadIdx.x & 63) == 0 && wave_rays) {
         unsigned long long* counters = p.counters + (size_t)(blockIdx.x % PT_COUNTER_SLOTS) * PT_COUNTER_STRIDE;
@@ -791,14 +882,14 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
         if (p.tile_cost) {
             unsigned cost = wave_trips;
             if (KIND == 2) cost = 8u * wave_trips + __builtin_amdgcn_readfirstlane(node_visits) + __builtin_amdgcn_readfirstlane(tri_tests);
-            if (KIND == 4) cost = 8u * wave_trips + (unsigned)(wave_tests >> 4);
+            if (KIND == 4 || KIND == 5) cost = 8u * wave_trips + (unsigned)(wave_tests >> 4);
             atomicAdd(&p.tile_cost[tile], cost);
         }
         if (KIND == 2 || KIND == 3) {
             atomicAdd(&counters[2], (unsigned long long)__builtin_amdgcn_readfirstlane(node_visits));
             atomicAdd(&counters[3], (unsigned long long)__builtin_amdgcn_readfirstlane(tri_tests));
         }
-        if (KIND == 4) atomicAdd(&counters[5], wave_tests);
+        if (KIND == 4 || KIND == 5) atomicAdd(&counters[5], wave_tests);
     }
 }
 
@@ -1101,7 +1192,8 @@ hipError_t pt_launch_render(const PtKernelParams& p, int program_kind, hipStream
     const dim3 grid(p.items ? p.max_items : window_tiles(p)), block(PT_TILE_THREADS);
     if (program_kind == 0) hipLaunchKernelGGL((pt_render_kernel<0, false>), grid, block, 0, stream, p);
     else if (p.shading_mode == 1) {
-        if (p.bvh_nodes_abs) hipLaunchKernelGGL((pt_render_kernel<2, true>), grid, block, 0, stream, p);
+        if (p.bvh_nodes_abs && p.lane_walk) hipLaunchKernelGGL((pt_render_kernel<5, true>), grid, block, 0, stream, p);
+        else if (p.bvh_nodes_abs) hipLaunchKernelGGL((pt_render_kernel<2, true>), grid, block, 0, stream, p);
         else hipLaunchKernelGGL((pt_render_kernel<1, true>), grid, block, 0, stream, p);
     }
     else if (p.grid_start) hipLaunchKernelGGL((pt_render_kernel<4, false>), grid, block, 0, stream, p);

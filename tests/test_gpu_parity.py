@@ -80,8 +80,26 @@ def test_multi_sample_dispatch_equals_frame_by_frame(tracer, name):
     t.program_destroy(prog)
 
 
-@pytest.mark.parametrize("accel", ["brute", "bvh"])
-def test_materials_mode_random_scene_against_oracle(tracer, accel):
+@pytest.fixture(scope="module")
+def wave_walk_tracer():
+    """A context whose materials mode walks the hierarchy once per wave (the default is once per lane)."""
+    import os
+    from pathtracer_amd import Tracer
+    old = os.environ.get("PT_LANE_WALK")
+    os.environ["PT_LANE_WALK"] = "0"
+    try:
+        t = Tracer(0)
+    finally:
+        if old is None:
+            del os.environ["PT_LANE_WALK"]
+        else:
+            os.environ["PT_LANE_WALK"] = old
+    yield t
+    t.close()
+
+
+@pytest.mark.parametrize("accel", ["brute", "bvh", "bvh_wave"])
+def test_materials_mode_random_scene_against_oracle(tracer, wave_walk_tracer, accel):
     """Diffuse/emissive mode on a seeded cloud of random triangles seen from inside (rays bounce from their hit points, hit emitters,
     leave through gaps): the all-triangles loop and the LBVH walk must both equal the CPU oracle bit for bit."""
     from pathtracer_amd import capi
@@ -101,9 +119,9 @@ def test_materials_mode_random_scene_against_oracle(tracer, accel):
     sph, _ = po.reference_spheres_and_materials()
     fx = {"width": W, "height": H, "variant": 1, "normal_mode": 1, "depth": 10, "camera": cam, "vertices": verts,
           "indices": idx, "spheres": sph, "materials": mats, "shading_mode": 1, "material_ids": mids}
-    t = tracer
+    t = wave_walk_tracer if accel == "bvh_wave" else tracer
     prog = setup_case(t, fx)
-    if accel == "bvh":
+    if accel != "brute":
         t.build_accel()
         t.set_accel_mode(capi.ACCEL_BVH)
     else:
@@ -119,24 +137,29 @@ def test_materials_mode_random_scene_against_oracle(tracer, accel):
     assert n_bit_mismatch(img, ref) == 0
     assert st["rays"] == rays and rays > 2 * W * H * 3
     if accel == "bvh":
+        assert st["grid_triangle_tests"] > 0 and st["bvh_node_fetches"] == 0     # per-lane walk: records counted per ray
+    if accel == "bvh_wave":
         assert st["bvh_node_fetches"] > 0
     t.set_accel_mode(capi.ACCEL_AUTO)
     t.set_shading_mode(0)
     t.program_destroy(prog)
 
 
-def test_materials_golden_through_bvh(tracer):
+@pytest.mark.parametrize("walk", ["lane", "wave"])
+def test_materials_golden_through_bvh(tracer, wave_walk_tracer, walk):
     """The llvmpipe golden of the diffuse/emissive mode, traced through the LBVH with absolute boxes."""
     from pathtracer_amd import capi
     fx = load_case("cornell_materials_128")
-    t = tracer
+    t = tracer if walk == "lane" else wave_walk_tracer
     prog = setup_case(t, fx)
     t.build_accel()
     t.set_accel_mode(capi.ACCEL_BVH)
+    t.reset_stats()
     t.dispatch(1, 16, 1)
     t.finish()
     assert n_bit_mismatch(t.readback()[..., :3], fx["lp_rgb_16"]) == 0
-    assert t.stats()["bvh_node_fetches"] > 0
+    st = t.stats()
+    assert (st["grid_triangle_tests"] if walk == "lane" else st["bvh_node_fetches"]) > 0
     t.set_accel_mode(capi.ACCEL_AUTO)
     t.set_shading_mode(0)
     t.program_destroy(prog)
