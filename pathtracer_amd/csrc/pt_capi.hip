@@ -107,6 +107,7 @@ struct PtContext {
     int32_t wave_slots = 0;               // waves the device holds at once (CUs x 4 SIMDs x 8)
     float split_factor = -1.f;            // < 0: chosen per kernel family, see pt_dispatch
     bool primary_reuse = true;
+    int32_t lane_stack_limit = PT_LANE_STACK;  // PT_LANE_STACK_LIMIT=n (testing): a lane hands over to the per-wave walk earlier
     bool lane_walk = true;                // PT_LANE_WALK=0: materials mode walks the hierarchy once per wave, not per lane
     bool auto_grid = true;                // PT_AUTO_GRID=0: PT_ACCEL_AUTO never picks the direction grid (for comparisons)
     bool keep_unreachable = false;        // PT_KEEP_UNREACHABLE=1: the loop walks all records (to measure the compaction)
@@ -400,6 +401,7 @@ PtStatus fill_params(PtContext* ctx, PtKernelParams* p, const Program** prog_out
             p->material_ids = ctx->d_material_ids;
             if (use_bvh) {
                 p->lane_walk = ctx->lane_walk ? 1 : 0;
+                p->lane_stack_limit = ctx->lane_stack_limit;
                 p->bvh_nodes_abs = ctx->bvh.nodes_abs;
                 p->bvh_tris_abs = ctx->bvh.sorted_tris_abs;
                 p->bvh_ids = ctx->bvh.sorted_ids;
@@ -484,6 +486,7 @@ PtStatus pt_create(int32_t device, PtContext** out_ctx) {
     if (const char* g = getenv("PT_AUTO_GRID")) ctx->auto_grid = g[0] != '0';
     if (const char* g = getenv("PT_GRID_RES")) ctx->grid_res_override = atoi(g);
     if (const char* l = getenv("PT_LANE_WALK")) ctx->lane_walk = l[0] != '0';
+    if (const char* l = getenv("PT_LANE_STACK_LIMIT")) ctx->lane_stack_limit = std::max(0, std::min(PT_LANE_STACK, atoi(l)));
     if (const char* k = getenv("PT_KEEP_UNREACHABLE")) ctx->keep_unreachable = k[0] == '1';
     if (const char* f = getenv("PT_SPLIT_FACTOR")) ctx->split_factor = (float)atof(f);  // for experiments
     *out_ctx = ctx;

@@ -34,6 +34,7 @@ struct PtTriRecordLayout {
 #define PT_BVH_LEAF_MAX 4
 #endif
 #define PT_BVH_STACK 96
+#define PT_LANE_STACK 24  // per-lane walk: stack entries per lane (LDS); deeper paths fall back to the per-wave walk
 // PT_ACCEL_AUTO walks the hierarchy above these triangle counts (measured: 36 triangles: loop = walk for camera-origin rays,
 // loop 1.3x faster for rays with their own origins; 64 triangles: walk 2.8x faster; 968: 40x)
 #define PT_BVH_AUTO_MIN_TRIANGLES 48
@@ -151,6 +152,7 @@ struct PtKernelParams {
     const int32_t* bvh_ids;             // triangle id of each leaf-order record
     const float* bvh_nodes_abs;         // LBVH records with absolute boxes (rays with their own origin)
     int32_t lane_walk;                  // 1: one hierarchy walk per lane (incoherent rays) instead of one per wave
+    int32_t lane_stack_limit;           // entries of a lane's stack that may be used (<= PT_LANE_STACK)
     const float* bvh_tris_abs;          // a, e1, e2 records in leaf order
     const float* spheres;               // 10 x (cx, cy, cz, r)
     const float* src;                   // RGBA32F image read (previous result)

@@ -455,7 +455,6 @@ __device__ __forceinline__ Hit intersect_bvh(const PtKernelParams& p, v3 ro, v3 
 // the wave. Same padded boxes, same slab arithmetic, same exact triangle test with the explicit lowest-id rule as the
 // per-wave walk. A lane whose stack would overflow (very deep hierarchy) reports it; the caller repeats that lane's query
 // with the per-wave walk, which has room for any hierarchy.
-#define PT_LANE_STACK 24
 __device__ __forceinline__ Hit intersect_bvh_lanes(const PtKernelParams& p, v3 ro, v3 rd, uint32_t* __restrict__ lstack, bool& overflow,
                                                    unsigned& steps) {
     Hit h;
@@ -493,7 +492,7 @@ __device__ __forceinline__ Hit intersect_bvh_lanes(const PtKernelParams& p, v3 r
             const uint32_t lref = __float_as_uint(n3.x), rref = __float_as_uint(n3.y);
             if (hl && hr) {
                 const bool left_first = lnear <= rnear;
-                if (sp >= PT_LANE_STACK) { overflow = true; return h; }
+                if (sp >= p.lane_stack_limit) { overflow = true; return h; }
                 my[sp * 64] = left_first ? rref : lref;
                 ++sp;
                 ref = left_first ? lref : rref;
@@ -885,7 +884,7 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
             if (KIND == 4 || KIND == 5) cost = 8u * wave_trips + (unsigned)(wave_tests >> 4);
             atomicAdd(&p.tile_cost[tile], cost);
         }
-        if (KIND == 2 || KIND == 3) {
+        if (KIND == 2 || KIND == 3 || KIND == 5) {  // 5: what the per-wave walk did for lanes whose own stack was full
             atomicAdd(&counters[2], (unsigned long long)__builtin_amdgcn_readfirstlane(node_visits));
             atomicAdd(&counters[3], (unsigned long long)__builtin_amdgcn_readfirstlane(tri_tests));
         }

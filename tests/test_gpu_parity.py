@@ -145,6 +145,38 @@ def test_materials_mode_random_scene_against_oracle(tracer, wave_walk_tracer, ac
     t.program_destroy(prog)
 
 
+@pytest.mark.parametrize("limit", [0, 2, 5])
+def test_lane_walk_hands_over_when_its_stack_is_full(limit):
+    """The per-lane walk keeps at most 24 pending nodes per lane; a lane that would need more repeats its query with the
+    per-wave walk. With the limit lowered to 0, 2 or 5 entries that hand-over happens all the time: the image must still
+    equal the oracle, and the per-wave counters show that it ran."""
+    import os
+    from pathtracer_amd import Tracer, capi
+    old = os.environ.get("PT_LANE_STACK_LIMIT")
+    os.environ["PT_LANE_STACK_LIMIT"] = str(limit)
+    try:
+        t = Tracer(0)
+    finally:
+        if old is None:
+            del os.environ["PT_LANE_STACK_LIMIT"]
+        else:
+            os.environ["PT_LANE_STACK_LIMIT"] = old
+    try:
+        fx = load_case("cornell_materials_128")
+        prog = setup_case(t, fx)
+        t.build_accel()
+        t.set_accel_mode(capi.ACCEL_BVH)
+        t.reset_stats()
+        t.dispatch(1, 16, 1)
+        t.finish()
+        assert n_bit_mismatch(t.readback()[..., :3], fx["lp_rgb_16"]) == 0
+        st = t.stats()
+        assert st["grid_triangle_tests"] > 0 and st["bvh_node_fetches"] > 0
+        t.program_destroy(prog)
+    finally:
+        t.close()
+
+
 @pytest.mark.parametrize("walk", ["lane", "wave"])
 def test_materials_golden_through_bvh(tracer, wave_walk_tracer, walk):
     """The llvmpipe golden of the diffuse/emissive mode, traced through the LBVH with absolute boxes."""
