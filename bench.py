@@ -227,8 +227,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": {"cornell": "synthetic camera on the reference cornell_box.obj", "instanced": "synthetic: 254 jittered instances of the reference suzanne.obj (fixed LCG seed)"}.get(args.workload, "reference OBJ asset, reference camera"),
-            "config": {"workload": f"{scene.name} {W}x{H}, {spp} spp per GPU per step, depth 10, "
-                                   f"{scene.num_triangles} triangles, closest hit through the direction grid (PT_ACCEL_AUTO)",
+            "config": {"workload": f"{scene.name} {W}x{H}, {spp} spp per GPU per step, depth 10, " +
+                                   (f"{scene.num_triangles} triangles, closest hit through the direction grid (PT_ACCEL_AUTO)"
+                                    if scene.program == 1 else "the reference's 10 spheres (IntersectWorld)"),
                        "parallelism": "single GPU" if world == 1 else f"sample split over {world} GPUs + RCCL all-reduce"},
             "rays_definition": "closest-hit queries as the reference counts them: one per bounce-loop iteration of every sample "
                                "(PathTracer.cpp:947). The shader has no pixel jitter, so the first query of every sample of a pixel "
