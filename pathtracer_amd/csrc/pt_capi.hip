@@ -53,6 +53,9 @@ struct PtContext {
 
     // scene
     float* d_spheres = nullptr;
+    float* d_sphere_recs = nullptr;   // 10 x 8: direction-independent terms of the sphere test for sphere_recs_ro
+    bool sphere_recs_valid = false;
+    float sphere_recs_ro[3] = {0, 0, 0};
     float* d_materials = nullptr;
     int32_t num_materials = 0;
     bool have_spheres = false;
@@ -422,7 +425,13 @@ PtStatus fill_params(PtContext* ctx, PtKernelParams* p, const Program** prog_out
         }
     } else {
         PT_REQUIRE(ctx->have_spheres, PT_ERR_STATE, "no spheres uploaded: call pt_upload_spheres first");
-        p->spheres = ctx->d_spheres;
+        if (!ctx->sphere_recs_valid || memcmp(u.camera_position, ctx->sphere_recs_ro, sizeof ctx->sphere_recs_ro) != 0) {
+            PT_HIP_TRY(pt_launch_prepare_spheres(ctx->d_spheres, u.camera_position, ctx->d_sphere_recs, ctx->stream));
+            memcpy(ctx->sphere_recs_ro, u.camera_position, sizeof ctx->sphere_recs_ro);
+            ctx->sphere_recs_valid = true;
+            ctx->list_valid = false;
+        }
+        p->spheres = ctx->d_sphere_recs;
     }
     *prog_out = prog;
     return PT_OK;
@@ -470,6 +479,7 @@ PtStatus pt_create(int32_t device, PtContext** out_ctx) {
     if (err == hipSuccess) err = hipMemsetAsync(ctx->d_counters, 0, kCounterBytes, ctx->own_stream);
     if (err == hipSuccess) err = hipStreamSynchronize(ctx->own_stream);
     if (err == hipSuccess) err = hipMalloc(&ctx->d_spheres, 40 * sizeof(float));
+    if (err == hipSuccess) err = hipMalloc(&ctx->d_sphere_recs, 80 * sizeof(float));
     if (err == hipSuccess) err = hipEventCreate(&ctx->ev_start);
     if (err == hipSuccess) err = hipEventCreate(&ctx->ev_stop);
     if (err != hipSuccess) {
@@ -500,6 +510,7 @@ PtStatus pt_destroy(PtContext* ctx) {
     free_target(ctx);
     free_mesh(ctx);
     if (ctx->d_spheres) (void)hipFree(ctx->d_spheres);
+    if (ctx->d_sphere_recs) (void)hipFree(ctx->d_sphere_recs);
     if (ctx->d_materials) (void)hipFree(ctx->d_materials);
     if (ctx->d_grid_estimate) (void)hipFree(ctx->d_grid_estimate);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
@@ -559,6 +570,7 @@ PtStatus pt_upload_spheres(PtContext* ctx, const float* xyzr, int32_t count) {
     PT_HIP_TRY(hipMemcpyAsync(ctx->d_spheres, xyzr, 40 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->have_spheres = true;
+    ctx->sphere_recs_valid = false;
     return PT_OK;
 }
 

@@ -154,7 +154,7 @@ struct PtKernelParams {
     int32_t lane_walk;                  // 1: one hierarchy walk per lane (incoherent rays) instead of one per wave
     int32_t lane_stack_limit;           // entries of a lane's stack that may be used (<= PT_LANE_STACK)
     const float* bvh_tris_abs;          // a, e1, e2 records in leaf order
-    const float* spheres;               // 10 x (cx, cy, cz, r)
+    const float* spheres;               // 10 x 8 floats: per-sphere records for the current camera position (pt_prepare_spheres_kernel)
     const float* src;                   // RGBA32F image read (previous result)
     float* dst;                         // RGBA32F image written
     unsigned long long* counters;       // PT_COUNTER_SLOTS x PT_COUNTER_STRIDE: per slot [0] rays, [1] lane slots spent (wave loop trips x 64),
@@ -173,6 +173,8 @@ struct PtKernelParams {
 hipError_t pt_launch_prepare_triangles(const float* vertices, const uint32_t* indices, int32_t num_triangles,
                                        const float ro[3], float* tris, float* vnormals, float* gnormals, float* cull,
                                        float* tris_abs, hipStream_t stream);
+// recs (10 x 8 floats) <- the direction-independent terms of the sphere test for ray origin ro
+hipError_t pt_launch_prepare_spheres(const float* spheres, const float ro[3], float* recs, hipStream_t stream);
 // live <- the records of `tris` that any camera ray can hit at all (e2r > 0), order kept, zero padding after; *live_count <- how many
 hipError_t pt_launch_compact_triangles(const float* tris, int32_t num_triangles, float* live, uint32_t* live_count, hipStream_t stream);
 hipError_t pt_launch_fill_rgba(float* img, size_t num_pixels, float r, float g, float b, float a, hipStream_t stream);

@@ -581,28 +581,30 @@ __device__ __forceinline__ Hit intersect_grid(const PtKernelParams& p, v3 rd, un
     return h;
 }
 
-// fs:83-121. `ro` is the camera position for every ray. Returns the hit normal through `n`.
-__device__ __forceinline__ Hit intersect_world(const float* __restrict__ spheres, v3 ro, v3 rd, v3& n) {
+// fs:83-121. The ray origin is the camera position for every ray, so the terms of the sphere test that do not involve the
+// direction are taken from a per-sphere record made once per camera position (pt_prepare_spheres_kernel: to = ro - centre,
+// C = dot(to, to) - r*r, 1/r; the same fp32 operations the shader performs per ray). The normal (fs:111) is formed once,
+// for the sphere that ends up closest. Returns it through `n`.
+__device__ __forceinline__ Hit intersect_world(const float* __restrict__ sphere_recs, v3 ro, v3 rd, v3& n) {
     Hit h;
     h.t = 1.0e38f; h.id = -1; h.u = 0.f; h.v = 0.f; h.ood = 0.f;
+    const ScalarView recs = scalar_view(reinterpret_cast<const float4*>(sphere_recs));
 #pragma unroll
     for (int obj = 0; obj < 10; ++obj) {
-        const v3 center = V(spheres[4 * obj], spheres[4 * obj + 1], spheres[4 * obj + 2]);
-        const float radius = spheres[4 * obj + 3];
-        const v3 to = ro - center;
-        const float B = -dot3(to, rd);
-        const float C = dot3(to, to) - radius * radius;
-        const float disc = B * B - C;
+        const float4 r0 = recs[2 * obj];  // to.xyz, C
+        const float B = -dot3(V(r0.x, r0.y, r0.z), rd);
+        const float disc = B * B - r0.w;
         if (disc > 0.0f) {
             const float root = __builtin_sqrtf(disc);
             float temp = B - root;
             temp = temp > 0.0f ? temp : (B + root);
-            if (temp > 0.0f && temp < h.t) {
-                const v3 p = ro + rd * temp;
-                n = (p - center) * (1.0f / radius);
-                h.t = temp; h.id = obj;
-            }
+            if (temp > 0.0f && temp < h.t) { h.t = temp; h.id = obj; }
         }
+    }
+    if (h.id >= 0) {
+        const float4 r1 = reinterpret_cast<const float4*>(sphere_recs)[2 * h.id + 1];  // centre.xyz, 1/radius
+        const v3 p = ro + rd * h.t;
+        n = (p - V(r1.x, r1.y, r1.z)) * r1.w;
     }
     return h;
 }
@@ -980,6 +982,20 @@ __global__ __launch_bounds__(256) void pt_prepare_triangles_kernel(const float* 
     cr[8] = nca.z; cr[9] = front.x; cr[10] = front.y; cr[11] = front.z;
 }
 
+// Per-sphere records for intersect_world: [to.xyz, C] [centre.xyz, 1/radius] with to = ro - centre, C = dot(to,to) - r*r.
+__global__ void pt_prepare_spheres_kernel(const float* __restrict__ spheres, float rox, float roy, float roz, float* __restrict__ recs) {
+    const int obj = threadIdx.x;
+    if (obj >= 10) return;
+    const v3 center = V(spheres[4 * obj], spheres[4 * obj + 1], spheres[4 * obj + 2]);
+    const float radius = spheres[4 * obj + 3];
+    const v3 to = V(rox, roy, roz) - center;
+    float* r = recs + 8 * obj;
+    r[0] = to.x; r[1] = to.y; r[2] = to.z;
+    r[3] = dot3(to, to) - radius * radius;
+    r[4] = center.x; r[5] = center.y; r[6] = center.z;
+    r[7] = 1.0f / radius;
+}
+
 // Every ray starts at the camera (the shader never moves `ro`), so a hit's distance is e2r / det with e2r =
 // dot(e2, cross(ro - a, e1)) fixed per triangle; det >= 1e-4 is positive, so a triangle with e2r <= 0 (the camera is
 // behind its plane, or in it) yields t <= 0 for every ray and fails the shader's `temp > 0.0` (fs:156) always. Such
@@ -1151,6 +1167,11 @@ hipError_t pt_launch_prepare_triangles(const float* vertices, const uint32_t* in
     if (num_triangles <= 0) return hipSuccess;
     hipLaunchKernelGGL(pt_prepare_triangles_kernel, dim3((num_triangles + 255) / 256), dim3(256), 0, stream, vertices,
                        indices, num_triangles, ro[0], ro[1], ro[2], tris, vnormals, gnormals, cull, tris_abs);
+    return hipGetLastError();
+}
+
+hipError_t pt_launch_prepare_spheres(const float* spheres, const float ro[3], float* recs, hipStream_t stream) {
+    hipLaunchKernelGGL(pt_prepare_spheres_kernel, dim3(1), dim3(64), 0, stream, spheres, ro[0], ro[1], ro[2], recs);
     return hipGetLastError();
 }
 
