@@ -33,7 +33,7 @@ PEAK_FP32_UNFUSED_TFLOPS = PEAK_FP32_VALU_TFLOPS / 2
 FLOP_PER_TRI_TEST = 43
 
 
-def cpu_baseline(scene, spp_hint, budget_s=12.0):
+def cpu_baseline(scene, spp_hint, budget_s=25.0):
     """The oracle (CPU restatement of the reference shader) on the same scene/camera/resolution, on a bounded sample:
     the full frame for as many passes as fit the time budget."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))

@@ -69,6 +69,7 @@ struct PtContext {
     float* d_gnormals = nullptr;
     float* d_cull = nullptr;
     float* d_tris_abs = nullptr;    // a, e1, e2 records (origin-independent)
+    float* d_tris_grid = nullptr;   // records of the direction-grid query (geometric normal in place of the index)
     int32_t* d_material_ids = nullptr;
     int32_t num_material_ids = 0;
     int32_t max_material_id = -1;
@@ -204,18 +205,20 @@ void free_bvh(PtContext* ctx) {
 
 void free_grid(PtContext* ctx) {
     PtGridBuild& g = ctx->grid;
-    void* ptrs[] = {g.cell_count, g.cell_start, g.list, g.scan_tmp, g.big_jobs, g.big_count};
+    void* ptrs[] = {g.cell_count, g.cell_start, g.cells, g.list, g.scan_tmp, g.big_jobs, g.big_count};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     g = PtGridBuild{};
     ctx->grid_built = false;
 }
 
-// Cube-map resolution per face: about four cells per triangle over the sphere, within [128, 2048]
+// Cube-map resolution per face: about sixteen cells per triangle over the sphere, within [512, 2048]
 int grid_resolution(const PtContext* ctx) {
     if (ctx->grid_res_override > 0) return ctx->grid_res_override;
-    int res = 128;
-    while (res < 2048 && (double)6 * res * res < 4.0 * (double)ctx->num_triangles) res *= 2;
+    // Measured: finer cells keep paying (fewer triangle tests per query) until the cell table falls out of the caches:
+    // 512 is best from 36 to a few thousand triangles, 2048 for a million.
+    int res = 512;
+    while (res < 2048 && (double)6 * res * res < 16.0 * (double)ctx->num_triangles) res *= 2;
     return res;
 }
 
@@ -241,14 +244,16 @@ PtStatus build_grid(PtContext* ctx) {
         g.scan_tmp_bytes = pt_grid_scan_temp_bytes(cells);
         PT_HIP_TRY(hipMalloc(&g.cell_count, (cells + 1) * sizeof(uint32_t)));
         PT_HIP_TRY(hipMalloc(&g.cell_start, (cells + 1) * sizeof(uint32_t)));
+        PT_HIP_TRY(hipMalloc(&g.cells, (cells + 1) * sizeof(uint32_t)));
         PT_HIP_TRY(hipMalloc(&g.scan_tmp, g.scan_tmp_bytes ? g.scan_tmp_bytes : 16));
         g.big_capacity = (uint32_t)std::min<size_t>((size_t)ctx->num_triangles * 6, (size_t)4 << 20);
         PT_HIP_TRY(hipMalloc(&g.big_jobs, (size_t)g.big_capacity * sizeof(uint32_t)));
         PT_HIP_TRY(hipMalloc(&g.big_count, sizeof(uint32_t)));
     }
     PT_HIP_TRY(pt_grid_count(g, ctx->d_tris, ctx->num_triangles, ctx->stream));
-    uint32_t total = 0;
+    uint32_t total = 0, entries = 0;  // list words needed (cells with two or more triangles); all (cell, triangle) entries
     PT_HIP_TRY(hipMemcpyAsync(&total, g.cell_start + cells, sizeof total, hipMemcpyDeviceToHost, ctx->stream));
+    PT_HIP_TRY(hipMemcpyAsync(&entries, g.cells + cells, sizeof entries, hipMemcpyDeviceToHost, ctx->stream));
     PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
     if ((size_t)total > g.list_capacity) {
         if (g.list) (void)hipFree(g.list);
@@ -259,7 +264,7 @@ PtStatus build_grid(PtContext* ctx) {
         g.list_capacity = cap;
     }
     PT_HIP_TRY(pt_grid_fill(g, ctx->d_tris, ctx->num_triangles, ctx->stream));
-    ctx->grid_entries = total;
+    ctx->grid_entries = entries;
     ctx->grid_built = true;
     return PT_OK;
 }
@@ -268,7 +273,7 @@ void free_mesh(PtContext* ctx) {
     free_bvh(ctx);
     free_grid(ctx);
     ctx->grid_wanted = false;
-    float** f[] = {&ctx->d_vertices, &ctx->d_tris, &ctx->d_vnormals, &ctx->d_gnormals, &ctx->d_cull, &ctx->d_tris_abs, &ctx->d_tris_live};
+    float** f[] = {&ctx->d_vertices, &ctx->d_tris, &ctx->d_vnormals, &ctx->d_gnormals, &ctx->d_cull, &ctx->d_tris_abs, &ctx->d_tris_live, &ctx->d_tris_grid};
     if (ctx->d_live_count) (void)hipFree(ctx->d_live_count);
     ctx->d_live_count = nullptr;
     for (float** q : f) {
@@ -290,7 +295,7 @@ PtStatus ensure_records(PtContext* ctx) {
     const float* ro = ctx->uniforms.camera_position;
     if (ctx->records_valid && memcmp(ro, ctx->records_ro, sizeof ctx->records_ro) == 0) return PT_OK;
     PT_HIP_TRY(pt_launch_prepare_triangles(ctx->d_vertices, ctx->d_indices, ctx->num_triangles, ro, ctx->d_tris,
-                                           ctx->d_vnormals, ctx->d_gnormals, ctx->d_cull, ctx->d_tris_abs, ctx->stream));
+                                           ctx->d_vnormals, ctx->d_gnormals, ctx->d_cull, ctx->d_tris_abs, ctx->d_tris_grid, ctx->stream));
     // what is derived from the records is brought up to date when a dispatch actually uses it (ensure_* below)
     ctx->live_valid = false;
     ctx->bvh_emit_valid = false;
@@ -387,9 +392,9 @@ PtStatus fill_params(PtContext* ctx, PtKernelParams* p, const Program** prog_out
             if (bs != PT_OK) return bs;
         }
         if (use_grid) {
-            p->grid_start = ctx->grid.cell_start;
+            p->grid_cells = ctx->grid.cells;
             p->grid_list = ctx->grid.list;
-            p->grid_tris = ctx->d_tris;
+            p->grid_tris = ctx->d_tris_grid;
             p->grid_res = ctx->grid.res;
         } else if (ctx->shading_mode == PT_SHADE_MATERIALS) {
             PT_REQUIRE(ctx->accel_mode != PT_ACCEL_CULL, PT_ERR_STATE, "PT_ACCEL_CULL serves rays from the camera only; PT_SHADE_MATERIALS moves the origin");
@@ -419,7 +424,7 @@ PtStatus fill_params(PtContext* ctx, PtKernelParams* p, const Program** prog_out
             p->live_count = nullptr;
         }
         // whatever kernel ends up walking the compacted array (the loop of the render or of the primary-hit kernel)
-        if (p->live_count && !p->grid_start && !p->bvh_nodes) {
+        if (p->live_count && !p->grid_cells && !p->bvh_nodes) {
             PtStatus ls = ensure_live(ctx);
             if (ls != PT_OK) return ls;
         }
@@ -612,6 +617,7 @@ PtStatus pt_upload_mesh(PtContext* ctx, const float* vertices, int32_t num_verti
     PT_HIP_TRY(hipMalloc(&ctx->d_gnormals, nt * 3 * sizeof(float)));
     PT_HIP_TRY(hipMalloc(&ctx->d_cull, nt * PT_CULL_FLOATS * sizeof(float)));
     PT_HIP_TRY(hipMalloc(&ctx->d_tris_abs, (nt + PT_TRI_PAD) * PT_TRI_FLOATS * sizeof(float)));
+    PT_HIP_TRY(hipMalloc(&ctx->d_tris_grid, nt * PT_TRI_FLOATS * sizeof(float)));
     PT_HIP_TRY(hipMemsetAsync(ctx->d_tris_abs + nt * PT_TRI_FLOATS, 0, PT_TRI_PAD * PT_TRI_FLOATS * sizeof(float), ctx->stream));
     PT_HIP_TRY(hipMemcpyAsync(ctx->d_vertices, vertices, (size_t)num_vertices * 6 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     PT_HIP_TRY(hipMemcpyAsync(ctx->d_indices, indices, nt * 3 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));

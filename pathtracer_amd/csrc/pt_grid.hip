@@ -140,22 +140,42 @@ __device__ __forceinline__ bool cell_touched(const FaceJob& job, int res, int iu
     return true;
 }
 
+// What a query reads (see intersect_grid in pt_kernels.hip): one word per cell --
+//   PT_GRID_EMPTY                 no triangle
+//   id            (top bit clear) exactly one triangle: the cell IS the list, no second fetch
+//   1<<31 | begin                 two or more: list[begin...], the last entry of a cell carries the top bit
+// so only cells with two or more triangles take list space (cell_start = prefix sums of those counts).
 template <bool COUNT>
 __device__ __forceinline__ void enter(int res, int f, int iu, int iv, uint32_t id, uint32_t* __restrict__ cell_count,
-                                      const uint32_t* __restrict__ cell_start, uint32_t* __restrict__ list) {
+                                      const uint32_t* __restrict__ cell_start, uint32_t* __restrict__ list, uint32_t* __restrict__ cells) {
     const size_t cell = ((size_t)f * res + iv) * res + iu;
-    if (COUNT) atomicAdd(&cell_count[cell], 1u);
-    else list[cell_start[cell] + atomicAdd(&cell_count[cell], 1u)] = id;
+    if (COUNT) {
+        atomicAdd(&cell_count[cell], 1u);
+        return;
+    }
+    const uint32_t begin = cell_start[cell], need = cell_start[cell + 1] - begin;
+    if (need == 0u) {
+        cells[cell] = id;  // the cell's only triangle
+    } else {
+        const uint32_t pos = atomicAdd(&cell_count[cell], 1u);
+        list[begin + pos] = id | (pos + 1u == need ? 0x80000000u : 0u);
+        if (pos == 0u) cells[cell] = 0x80000000u | begin;
+    }
 }
+
+// list space of a cell: none for 0 or 1 triangles
+struct ListNeed {
+    __host__ __device__ __forceinline__ uint32_t operator()(const uint32_t& count) const { return count >= 2u ? count : 0u; }
+};
 
 constexpr int kInlineCells = 48;  // jobs covering more cells than this go to the queue of big jobs
 
-// One thread per (triangle, face). COUNT = true: cell_count[cell]++; false: list[cell_start[cell] + cursor[cell]++] = triangle.
+// One thread per (triangle, face). COUNT = true: cell_count[cell]++; false: the triangle is entered into the cell (enter()).
 // A job whose bounding box covers many cells is not walked here but queued for grid_bin_big (one workgroup per job).
 template <bool COUNT>
 __global__ __launch_bounds__(128) void grid_bin_triangles(const float4* __restrict__ tris, int n, int res, uint32_t* __restrict__ cell_count,
                                                           const uint32_t* __restrict__ cell_start, uint32_t* __restrict__ list,
-                                                          uint32_t* __restrict__ big_jobs, uint32_t* __restrict__ big_count, uint32_t big_capacity) {
+                                                          uint32_t* __restrict__ cells_out, uint32_t* __restrict__ big_jobs, uint32_t* __restrict__ big_count, uint32_t big_capacity) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n * 6) return;
     const int i = j / 6, f = j % 6;
@@ -172,13 +192,13 @@ __global__ __launch_bounds__(128) void grid_bin_triangles(const float4* __restri
     }
     for (int iv = job.iv0; iv <= job.iv1; ++iv)
         for (int iu = job.iu0; iu <= job.iu1; ++iu)
-            if (cell_touched(job, res, iu, iv)) enter<COUNT>(res, f, iu, iv, (uint32_t)i, cell_count, cell_start, list);
+            if (cell_touched(job, res, iu, iv)) enter<COUNT>(res, f, iu, iv, (uint32_t)i, cell_count, cell_start, list, cells_out);
 }
 
 template <bool COUNT>
 __global__ __launch_bounds__(256) void grid_bin_big(const float4* __restrict__ tris, int res, uint32_t* __restrict__ cell_count,
                                                     const uint32_t* __restrict__ cell_start, uint32_t* __restrict__ list,
-                                                    const uint32_t* __restrict__ big_jobs, const uint32_t* __restrict__ big_count, uint32_t big_capacity) {
+                                                    uint32_t* __restrict__ cells_out, const uint32_t* __restrict__ big_jobs, const uint32_t* __restrict__ big_count, uint32_t big_capacity) {
     const uint32_t queued = *big_count < big_capacity ? *big_count : big_capacity;
     for (uint32_t slot = blockIdx.x; slot < queued; slot += gridDim.x) {
         const int j = (int)big_jobs[slot], i = j / 6, f = j % 6;
@@ -187,7 +207,7 @@ __global__ __launch_bounds__(256) void grid_bin_big(const float4* __restrict__ t
         const int wu = job.iu1 - job.iu0 + 1, cells = wu * (job.iv1 - job.iv0 + 1);
         for (int c = threadIdx.x; c < cells; c += blockDim.x) {
             const int iu = job.iu0 + c % wu, iv = job.iv0 + c / wu;
-            if (cell_touched(job, res, iu, iv)) enter<COUNT>(res, f, iu, iv, (uint32_t)i, cell_count, cell_start, list);
+            if (cell_touched(job, res, iu, iv)) enter<COUNT>(res, f, iu, iv, (uint32_t)i, cell_count, cell_start, list, cells_out);
         }
     }
 }
@@ -220,9 +240,9 @@ hipError_t bin_all(const PtGridBuild& g, const float* tris, int32_t n, hipStream
     const int jobs = n * 6;
     const float4* t4 = reinterpret_cast<const float4*>(tris);
     hipLaunchKernelGGL(grid_bin_triangles<COUNT>, dim3((jobs + 127) / 128), dim3(128), 0, stream, t4, n, g.res, g.cell_count, g.cell_start, g.list,
-                       g.big_jobs, g.big_count, g.big_capacity);
-    hipLaunchKernelGGL(grid_bin_big<COUNT>, dim3(2048), dim3(256), 0, stream, t4, g.res, g.cell_count, g.cell_start, g.list, g.big_jobs, g.big_count,
-                       g.big_capacity);
+                       g.cells, g.big_jobs, g.big_count, g.big_capacity);
+    hipLaunchKernelGGL(grid_bin_big<COUNT>, dim3(2048), dim3(256), 0, stream, t4, g.res, g.cell_count, g.cell_start, g.list, g.cells, g.big_jobs,
+                       g.big_count, g.big_capacity);
     return hipGetLastError();
 }
 
@@ -231,7 +251,10 @@ hipError_t bin_all(const PtGridBuild& g, const float* tris, int32_t n, hipStream
 size_t pt_grid_scan_temp_bytes(size_t cells) {
     size_t bytes = 0;
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)(cells + 1), nullptr);
-    return bytes;
+    size_t bytes2 = 0;
+    hipcub::TransformInputIterator<uint32_t, ListNeed, const uint32_t*> need((const uint32_t*)nullptr, ListNeed());
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes2, need, (uint32_t*)nullptr, (int)(cells + 1), nullptr);
+    return bytes > bytes2 ? bytes : bytes2;
 }
 
 hipError_t pt_grid_estimate(const float* tris, int32_t n, int res, unsigned long long* total, hipStream_t stream) {
@@ -246,12 +269,20 @@ hipError_t pt_grid_count(const PtGridBuild& g, const float* tris, int32_t n, hip
     const size_t cells = (size_t)6 * g.res * g.res;
     hipError_t e = bin_all<true>(g, tris, n, stream);
     if (e != hipSuccess) return e;
+    // all entries (cells[cells] <- their number; `cells` is rewritten by the fill pass), then the list space
     size_t bytes = g.scan_tmp_bytes;
-    e = hipcub::DeviceScan::ExclusiveSum(g.scan_tmp, bytes, g.cell_count, g.cell_start, (int)(cells + 1), stream);
+    e = hipcub::DeviceScan::ExclusiveSum(g.scan_tmp, bytes, g.cell_count, g.cells, (int)(cells + 1), stream);
+    if (e != hipSuccess) return e;
+    bytes = g.scan_tmp_bytes;
+    hipcub::TransformInputIterator<uint32_t, ListNeed, const uint32_t*> need(g.cell_count, ListNeed());
+    e = hipcub::DeviceScan::ExclusiveSum(g.scan_tmp, bytes, need, g.cell_start, (int)(cells + 1), stream);
     if (e != hipSuccess) return e;
     return hipGetLastError();
 }
 
 hipError_t pt_grid_fill(const PtGridBuild& g, const float* tris, int32_t n, hipStream_t stream) {
+    const size_t cells = (size_t)6 * g.res * g.res;
+    hipError_t e = hipMemsetAsync(g.cells, 0xff, (cells + 1) * sizeof(uint32_t), stream);  // PT_GRID_EMPTY
+    if (e != hipSuccess) return e;
     return bin_all<false>(g, tris, n, stream);
 }

@@ -71,11 +71,13 @@ struct PtBvhBuild {
 };
 
 // Direction grid (pt_grid.hip): for rays that all start at the camera, cube-map cells -> triangles a direction of the
-// cell could hit. cell_start has 6*res*res + 1 entries (exclusive prefix sums; the last is the list length).
+// cell could hit.
+#define PT_GRID_EMPTY 0xffffffffu
 struct PtGridBuild {
     int32_t res;
     uint32_t* cell_count;   // 6*res*res + 1: counts during the build, fill cursors afterwards
-    uint32_t* cell_start;   // 6*res*res + 1
+    uint32_t* cell_start;   // 6*res*res + 1: prefix sums of the list space of the cells (build only)
+    uint32_t* cells;        // 6*res*res + 1: what a query reads (PT_GRID_EMPTY, the one triangle, or 1<<31 | list position)
     uint32_t* list;         // triangle indices
     size_t list_capacity;   // entries
     void* scan_tmp;
@@ -87,9 +89,9 @@ struct PtGridBuild {
 size_t pt_grid_scan_temp_bytes(size_t cells);
 // *total <- an upper bound of the list length at resolution res (bounding-box cells of every triangle and face)
 hipError_t pt_grid_estimate(const float* tris, int32_t n, int res, unsigned long long* total, hipStream_t stream);
-// counts the entries of every cell and leaves their prefix sums in cell_start (read cell_start[cells] for the list length)
+// counts the entries of every cell; afterwards cells[6*res*res] = all entries, cell_start[6*res*res] = the list length needed
 hipError_t pt_grid_count(const PtGridBuild& g, const float* tris, int32_t n, hipStream_t stream);
-// fills list (capacity must cover cell_start[cells])
+// fills cells and list (capacity must cover cell_start[6*res*res])
 hipError_t pt_grid_fill(const PtGridBuild& g, const float* tris, int32_t n, hipStream_t stream);
 
 size_t pt_bvh_sort_temp_bytes(int32_t n);
@@ -137,9 +139,9 @@ struct PtKernelParams {
     const float* vnormals;              // num_triangles x 9: the three vertex normals (na, nb, nc)
     const float* gnormals;              // num_triangles x 3: normalize(cross(e1, e2))
     const float* cull;                  // num_triangles x PT_CULL_FLOATS, or null = no wave-level culling
-    const uint32_t* grid_start;         // direction grid: 6*res*res + 1 prefix sums, or null
-    const uint32_t* grid_list;          // triangle indices of the cells
-    const float* grid_tris;             // all records (origin-relative), indexed by triangle
+    const uint32_t* grid_cells;         // direction grid: one word per cell (see PtGridBuild::cells), or null
+    const uint32_t* grid_list;          // triangle indices of the cells with two or more (last one of a cell: top bit set)
+    const float* grid_tris;             // per triangle: e1, e2, ap, r, e2r, geometric normal (origin-relative)
     int32_t grid_res;
     const uint32_t* live_count;         // device scalar: records in `tris` when it is the compacted array; null = num_triangles
     const float* tris_abs;              // num_triangles x PT_TRI_FLOATS: a, e1, e2 (for rays with their own origin)
@@ -172,7 +174,7 @@ struct PtKernelParams {
 // Launchers (defined in pt_kernels.hip). All are asynchronous on `stream`.
 hipError_t pt_launch_prepare_triangles(const float* vertices, const uint32_t* indices, int32_t num_triangles,
                                        const float ro[3], float* tris, float* vnormals, float* gnormals, float* cull,
-                                       float* tris_abs, hipStream_t stream);
+                                       float* tris_abs, float* tris_grid, hipStream_t stream);
 // recs (10 x 8 floats) <- the direction-independent terms of the sphere test for ray origin ro
 hipError_t pt_launch_prepare_spheres(const float* spheres, const float ro[3], float* recs, hipStream_t stream);
 // live <- the records of `tris` that any camera ray can hit at all (e2r > 0), order kept, zero padding after; *live_count <- how many

@@ -536,7 +536,8 @@ __device__ __forceinline__ Hit intersect_bvh_lanes(const PtKernelParams& p, v3 r
 // Direction-grid query (see pt_grid.hip): the cell of the ray's direction lists the triangles it can hit at all. Every
 // lane walks its own list (lanes of a wave look in different cells), records come through per-lane vector loads; the
 // index of the next entry is fetched while the current triangle is tested. Same exact test, explicit lowest-index rule.
-__device__ __forceinline__ Hit intersect_grid(const PtKernelParams& p, v3 rd, unsigned& tests) {
+// `gn` <- the accepted triangle's geometric normal, which travels in its record.
+__device__ __forceinline__ Hit intersect_grid(const PtKernelParams& p, v3 rd, unsigned& tests, v3& gn) {
     Hit h;
     h.t = 1.0e38f; h.id = -1; h.u = 0.f; h.v = 0.f; h.ood = 0.f;
     const float ax = __builtin_fabsf(rd.x), ay = __builtin_fabsf(rd.y), az = __builtin_fabsf(rd.z);
@@ -553,12 +554,22 @@ __device__ __forceinline__ Hit intersect_grid(const PtKernelParams& p, v3 rd, un
     iu = iu < 0 ? 0 : (iu >= res ? res - 1 : iu);
     iv = iv < 0 ? 0 : (iv >= res ? res - 1 : iv);
     const uint32_t cell = ((uint32_t)face * (uint32_t)res + (uint32_t)iv) * (uint32_t)res + (uint32_t)iu;  // < 6 * 2048^2
-    const uint32_t begin = p.grid_start[cell], end = p.grid_start[cell + 1];
+    // One word per cell: empty, the cell's only triangle (then the record is the very next fetch), or the position of its
+    // list, whose last entry carries the top bit.
+    uint32_t entry = p.grid_cells[cell];
+    if (entry == PT_GRID_EMPTY) return h;
     const float4* __restrict__ recs = reinterpret_cast<const float4*>(p.grid_tris);
-    uint32_t next = begin < end ? p.grid_list[begin] : 0u;
-    for (uint32_t k = begin; k < end; ++k) {
-        const uint32_t tri = next;
-        if (k + 1 < end) next = p.grid_list[k + 1];
+    uint32_t pos = 0u;
+    if (entry & 0x80000000u) {
+        pos = entry & 0x7fffffffu;
+        entry = p.grid_list[pos];
+    } else {
+        entry |= 0x80000000u;
+    }
+    for (;;) {
+        const uint32_t tri = entry & 0x7fffffffu;
+        const bool last = (entry & 0x80000000u) != 0u;
+        if (!last) entry = p.grid_list[++pos];  // fetched while this triangle is tested
         TriRec t;
         t.a = recs[4 * (size_t)tri]; t.b = recs[4 * (size_t)tri + 1]; t.c = recs[4 * (size_t)tri + 2]; t.d = recs[4 * (size_t)tri + 3];
         const v3 e1 = V(t.a.x, t.a.y, t.a.z);
@@ -574,9 +585,11 @@ __device__ __forceinline__ Hit intersect_grid(const PtKernelParams& p, v3 rd, un
             const float tt = t.d.x * ood;
             if (tt > 0.0f && (tt < h.t || (tt == h.t && (int)tri < h.id))) {
                 h.t = tt; h.id = (int)tri; h.u = u; h.v = v; h.ood = ood;
+                gn = V(t.d.y, t.d.z, t.d.w);
             }
         }
         ++tests;
+        if (last) break;
     }
     return h;
 }
@@ -772,10 +785,10 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
                 h = intersect_bvh_lanes(p, o, d, s_lane_stack[threadIdx.x >> 6], overflow, lane_tests);
                 if (overflow) h = intersect_bvh<true>(p, o, d, s_stack[threadIdx.x >> 6], node_visits, tri_tests);
             }
-            else h = intersect_grid(p, d, lane_tests);
+            else h = intersect_grid(p, d, lane_tests, n);
         }
         const bool hit = want && h.id >= 0;
-        if (hit && KIND != 0) n = mesh_normal(p, h);
+        if (hit && KIND != 0 && !(KIND == 4 && p.normal_mode != 0)) n = mesh_normal(p, h);  // (the grid's records hold the geometric normal)
         n_out = n; t_out = h.t; id_out = h.id;
         return hit;
     };
@@ -910,7 +923,7 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_primary_kernel(const PtKer
     unsigned nv = 0, tt = 0;
     if (KIND == 2) h = intersect_bvh<false>(p, ro, rd, s_stack[threadIdx.x >> 6], nv, tt);
     if (KIND == 3) h = intersect_mesh_culled(p, rd, in_window, load_cull(reinterpret_cast<const float4*>(p.cull), threadIdx.x & 63, p.num_triangles), tt);
-    if (KIND == 4) h = intersect_grid(p, rd, tt);
+    if (KIND == 4) h = intersect_grid(p, rd, tt, N);
     if (!in_window) return;
     if (p.out_ids) p.out_ids[pix] = h.id;
     if (p.out_t) p.out_t[pix] = h.t;
@@ -922,7 +935,7 @@ __global__ __launch_bounds__(256) void pt_prepare_triangles_kernel(const float* 
                                                                     float rox, float roy, float roz,
                                                                     float* __restrict__ tris, float* __restrict__ vnormals,
                                                                     float* __restrict__ gnormals, float* __restrict__ cull,
-                                                                    float* __restrict__ tris_abs) {
+                                                                    float* __restrict__ tris_abs, float* __restrict__ tris_grid) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float* pa = vertices + 6 * (size_t)indices[3 * i];
@@ -951,6 +964,11 @@ __global__ __launch_bounds__(256) void pt_prepare_triangles_kernel(const float* 
     vn[6] = pc[3]; vn[7] = pc[4]; vn[8] = pc[5];
     const v3 g = normalize3(cross3(e1, e2));
     gnormals[3 * (size_t)i] = g.x; gnormals[3 * (size_t)i + 1] = g.y; gnormals[3 * (size_t)i + 2] = g.z;
+    // record of the direction-grid query: the same twelve words and e2r, then the geometric normal instead of the index
+    // (the query knows the index from the cell), so a hit needs no further fetch
+    float* tg = tris_grid + (size_t)i * PT_TRI_FLOATS;
+    for (int k = 0; k < 13; ++k) tg[k] = t[k];
+    tg[13] = g.x; tg[14] = g.y; tg[15] = g.z;
 
     // Cull record: four unit normals of planes through the ray origin. A direction can only pass the exact test
     // when it lies on the inner side of the three edge planes (origin, two vertices) and sees the front of the
@@ -1163,10 +1181,10 @@ int window_tiles(const PtKernelParams& p) { return PT_TILES_ACROSS(p.win_w) * PT
 
 hipError_t pt_launch_prepare_triangles(const float* vertices, const uint32_t* indices, int32_t num_triangles,
                                        const float ro[3], float* tris, float* vnormals, float* gnormals, float* cull,
-                                       float* tris_abs, hipStream_t stream) {
+                                       float* tris_abs, float* tris_grid, hipStream_t stream) {
     if (num_triangles <= 0) return hipSuccess;
     hipLaunchKernelGGL(pt_prepare_triangles_kernel, dim3((num_triangles + 255) / 256), dim3(256), 0, stream, vertices,
-                       indices, num_triangles, ro[0], ro[1], ro[2], tris, vnormals, gnormals, cull, tris_abs);
+                       indices, num_triangles, ro[0], ro[1], ro[2], tris, vnormals, gnormals, cull, tris_abs, tris_grid);
     return hipGetLastError();
 }
 
@@ -1216,7 +1234,7 @@ hipError_t pt_launch_render(const PtKernelParams& p, int program_kind, hipStream
         else if (p.bvh_nodes_abs) hipLaunchKernelGGL((pt_render_kernel<2, true>), grid, block, 0, stream, p);
         else hipLaunchKernelGGL((pt_render_kernel<1, true>), grid, block, 0, stream, p);
     }
-    else if (p.grid_start) hipLaunchKernelGGL((pt_render_kernel<4, false>), grid, block, 0, stream, p);
+    else if (p.grid_cells) hipLaunchKernelGGL((pt_render_kernel<4, false>), grid, block, 0, stream, p);
     else if (p.bvh_nodes) hipLaunchKernelGGL((pt_render_kernel<2, false>), grid, block, 0, stream, p);
     else if (p.cull) hipLaunchKernelGGL((pt_render_kernel<3, false>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL((pt_render_kernel<1, false>), grid, block, 0, stream, p);
@@ -1228,7 +1246,7 @@ hipError_t pt_launch_render(const PtKernelParams& p, int program_kind, hipStream
 hipError_t pt_launch_primary(const PtKernelParams& p, int program_kind, hipStream_t stream) {
     if (p.win_w <= 0 || p.win_h <= 0) return hipSuccess;
     if (program_kind == 0) hipLaunchKernelGGL(pt_primary_kernel<0>, dim3(window_tiles(p)), dim3(PT_TILE_THREADS), 0, stream, p);
-    else if (p.grid_start) hipLaunchKernelGGL(pt_primary_kernel<4>, dim3(window_tiles(p)), dim3(PT_TILE_THREADS), 0, stream, p);
+    else if (p.grid_cells) hipLaunchKernelGGL(pt_primary_kernel<4>, dim3(window_tiles(p)), dim3(PT_TILE_THREADS), 0, stream, p);
     else if (p.bvh_nodes) hipLaunchKernelGGL(pt_primary_kernel<2>, dim3(window_tiles(p)), dim3(PT_TILE_THREADS), 0, stream, p);
     else if (p.cull) hipLaunchKernelGGL(pt_primary_kernel<3>, dim3(window_tiles(p)), dim3(PT_TILE_THREADS), 0, stream, p);
     else hipLaunchKernelGGL(pt_primary_kernel<1>, dim3(window_tiles(p)), dim3(PT_TILE_THREADS), 0, stream, p);

@@ -17,6 +17,7 @@ sys.path.insert(0, ROOT)
 VARIANTS = {
     "base": [],
     "vfirst": ["-DPT_V_VFIRST"],
+    "cur": [],
 }
 
 

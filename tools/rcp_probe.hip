@@ -1,0 +1,87 @@
+// Exhaustive check of cheaper correctly-rounded reciprocal / square-root sequences against the compiler's IEEE lowering,
+// under the product's floating-point flags (denormals flushed, no contraction). Every one of the 2^32 bit patterns is tried.
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fgpu-flush-denormals-to-zero -fno-fast-math tools/rcp_probe.hip -o tools/rcp_probe
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+
+__device__ __forceinline__ float rcp_nr1(float x) {
+    const float r = __builtin_amdgcn_rcpf(x);
+    const float e = __builtin_fmaf(-x, r, 1.0f);
+    const float q = __builtin_fmaf(e, r, r);
+    return __builtin_amdgcn_div_fixupf(q, x, 1.0f);
+}
+__device__ __forceinline__ float rcp_nr2(float x) {
+    float r = __builtin_amdgcn_rcpf(x);
+    float e = __builtin_fmaf(-x, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    e = __builtin_fmaf(-x, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    return __builtin_amdgcn_div_fixupf(r, x, 1.0f);
+}
+__device__ __forceinline__ float sqrt_nr(float x) {
+    // s ~ sqrt(x) from rsq, one coupled refinement, final residual correction
+    const float r = __builtin_amdgcn_rsqf(x);
+    float s = x * r;
+    const float h = 0.5f * r;
+    const float d = __builtin_fmaf(-s, s, x);
+    s = __builtin_fmaf(d, h, s);
+    return (x == 0.0f || x == __builtin_inff()) ? x : s;
+}
+
+// (m - 1) / (m + 1) for a mantissa m in [1, 2): refined reciprocal, quotient, one residual correction
+__device__ __forceinline__ float div_log2(float a, float b) {
+    float r = __builtin_amdgcn_rcpf(b);
+    r = __builtin_fmaf(__builtin_fmaf(-b, r, 1.0f), r, r);
+    const float q = a * r;
+    return __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
+}
+
+__global__ void probe_log2(unsigned long long* bad) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // every mantissa
+    if (i >= (1u << 23)) return;
+    const float m = __uint_as_float(i | 0x3f800000u);
+    const float a = m - 1.0f, b = m + 1.0f;
+    if (__float_as_uint(a / b) != __float_as_uint(div_log2(a, b))) atomicAdd(bad, 1ull);
+}
+
+struct Out { unsigned long long bad[3]; uint32_t first[3][4]; unsigned long long nan_bits[3]; };
+
+__global__ void probe(Out* out) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32); i += stride) {
+        const float x = __uint_as_float((uint32_t)i);
+        const float ref = 1.0f / x;
+        const float sref = __builtin_sqrtf(x);
+        const float c[3] = {rcp_nr1(x), rcp_nr2(x), sqrt_nr(x)};
+        const float r[3] = {ref, ref, sref};
+        for (int k = 0; k < 3; ++k) {
+            const bool both_nan = (c[k] != c[k]) && (r[k] != r[k]);
+            if (both_nan && __float_as_uint(c[k]) != __float_as_uint(r[k])) atomicAdd(&out->nan_bits[k], 1ull);  // NaN, but another NaN
+            if (__float_as_uint(c[k]) != __float_as_uint(r[k]) && !both_nan) {
+                const unsigned long long n = atomicAdd(&out->bad[k], 1ull);
+                if (n < 4) out->first[k][n] = (uint32_t)i;
+            }
+        }
+    }
+}
+
+int main() {
+    Out* d; Out h;
+    (void)hipMalloc(&d, sizeof(Out)); (void)hipMemset(d, 0, sizeof(Out));
+    hipLaunchKernelGGL(probe, dim3(256 * 16), dim3(256), 0, 0, d);
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(&h, d, sizeof(Out), hipMemcpyDeviceToHost);
+    const char* names[3] = {"rcp_nr1", "rcp_nr2", "sqrt_nr"};
+    for (int k = 0; k < 3; ++k) {
+        printf("{\"candidate\": \"%s\", \"mismatches\": %llu, \"first\": [", names[k], h.bad[k]);
+        for (int j = 0; j < 4 && (unsigned long long)j < h.bad[k]; ++j) printf("%s\"0x%08x\"", j ? ", " : "", h.first[k][j]);
+        printf("], \"nan_results_with_other_bits\": %llu}\n", h.nan_bits[k]);
+    }
+    unsigned long long* dbad; unsigned long long hbad = 0;
+    (void)hipMalloc(&dbad, 8); (void)hipMemset(dbad, 0, 8);
+    hipLaunchKernelGGL(probe_log2, dim3((1u << 23) / 256), dim3(256), 0, 0, dbad);
+    (void)hipMemcpy(&hbad, dbad, 8, hipMemcpyDeviceToHost);
+    printf("{\"candidate\": \"div_log2 over all 2^23 mantissas\", \"mismatches\": %llu}\n", hbad);
+    return 0;
+}
