@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 2
+#define PT_ABI_VERSION 3
 
 typedef enum PtStatus {
     PT_OK = 0,
@@ -223,6 +223,13 @@ PtStatus pt_readback_primary(PtContext* ctx, int32_t* ids, float* t);
 PtStatus pt_enable_timing(PtContext* ctx, int32_t enabled);
 PtStatus pt_get_stats(PtContext* ctx, PtStats* out);
 PtStatus pt_reset_stats(PtContext* ctx);
+/* No counterpart in the reference. The kernels form 1/x, sqrt(x) and the quotient inside their log2 with shorter
+ * instruction sequences than the compiler's IEEE division and square root; the results are required to be the same bit
+ * for bit (that is what keeps images identical to the shader's on llvmpipe). This runs every one of the 2^32 float
+ * inputs (2^23 mantissas for the quotient) through both on the context's device and returns how many differ:
+ * mismatches[0] reciprocal, [1] square root, [2] quotient. All three are 0 on a device the library supports.
+ * Takes about a tenth of a second. */
+PtStatus pt_selftest_arithmetic(PtContext* ctx, uint64_t mismatches[3]);
 
 #ifdef __cplusplus
 }

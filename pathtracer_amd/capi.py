@@ -74,6 +74,7 @@ SIGNATURES = {
     "pt_enable_timing": (C.c_int, [C.c_void_p, C.c_int32]),
     "pt_get_stats": (C.c_int, [C.c_void_p, C.POINTER(PtStats)]),
     "pt_reset_stats": (C.c_int, [C.c_void_p]),
+    "pt_selftest_arithmetic": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
 }
 
 _libs = {}
@@ -251,3 +252,9 @@ class Tracer:
 
     def reset_stats(self):
         check(self._lib.pt_reset_stats(self._ctx), self._lib)
+
+    def selftest_arithmetic(self):
+        """(reciprocal, square root, log2 quotient): inputs for which the kernels' short sequences differ from IEEE; all 0."""
+        out = (C.c_uint64 * 3)()
+        check(self._lib.pt_selftest_arithmetic(self._ctx, out), self._lib)
+        return tuple(int(v) for v in out)

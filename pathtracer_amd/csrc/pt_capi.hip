@@ -1040,5 +1040,22 @@ PtStatus pt_reset_stats(PtContext* ctx) {
     return PT_OK;
 }
 
+PtStatus pt_selftest_arithmetic(PtContext* ctx, uint64_t mismatches[3]) {
+    PtStatus s = bind(ctx);
+    if (s != PT_OK) return s;
+    PT_REQUIRE(mismatches != nullptr, PT_ERR_INVALID_ARGUMENT, "mismatches is null");
+    unsigned long long* d = nullptr;
+    PT_HIP_TRY(hipMalloc(&d, 3 * sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(d, 0, 3 * sizeof(unsigned long long), ctx->stream);
+    if (e == hipSuccess) e = pt_launch_arith_selftest(d, ctx->stream);
+    unsigned long long h[3] = {0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    PT_HIP_TRY(e);
+    for (int k = 0; k < 3; ++k) mismatches[k] = h[k];
+    return PT_OK;
+}
+
 }  // extern "C"
 #pragma GCC visibility pop

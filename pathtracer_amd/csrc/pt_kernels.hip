@@ -28,7 +28,31 @@ __device__ __forceinline__ float dot3(v3 a, v3 b) { return a.x * b.x + (a.y * b.
 __device__ __forceinline__ v3 cross3(v3 a, v3 b) {
     return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
-__device__ __forceinline__ v3 normalize3(v3 a) { return a * (1.0f / __builtin_sqrtf(dot3(a, a))); }
+// 1.0f / x, correctly rounded like the IEEE division, in four instructions instead of the division's twelve: hardware
+// reciprocal (1 ulp), one Newton step in fused arithmetic, and the division's own fix-up for zero, infinity and NaN.
+// Bit-identical to `1.0f / x` for every one of the 2^32 inputs under this build's flags (pt_arith_selftest_kernel runs them all).
+__device__ __forceinline__ float ieee_rcp(float x) {
+    const float r = __builtin_amdgcn_rcpf(x);
+    const float q = __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+    return __builtin_amdgcn_div_fixupf(q, x, 1.0f);
+}
+// sqrtf(x), correctly rounded: the compiler's own refinement (reciprocal square root, coupled Newton step, residual
+// correction) without its rescaling of tiny inputs, which take the compiler's full sequence instead. Bit-identical to
+// __builtin_sqrtf for all 2^32 inputs (pt_arith_selftest_kernel).
+__device__ __forceinline__ float ieee_sqrt(float x) {
+    const uint32_t xb = __float_as_uint(x);  // the short way serves +-0 and [2^-96, +inf] and NaN; the rest (tiny, negative) is rare
+    if ((xb - 0x0f800000u) >= 0x70800000u && (xb << 1) != 0u) return __builtin_sqrtf(x);
+    const float r = __builtin_amdgcn_rsqf(x);
+    float s = x * r;
+    float h = 0.5f * r;
+    const float e = __builtin_fmaf(-h, s, 0.5f);
+    s = __builtin_fmaf(s, e, s);
+    h = __builtin_fmaf(h, e, h);
+    const float d = __builtin_fmaf(-s, s, x);
+    s = __builtin_fmaf(d, h, s);
+    return (x == 0.0f || x == __builtin_inff()) ? x : s;
+}
+__device__ __forceinline__ v3 normalize3(v3 a) { return a * ieee_rcp(ieee_sqrt(dot3(a, a))); }
 __device__ __forceinline__ v3 reflect3(v3 i, v3 n) { return i - n * (2.0f * dot3(n, i)); }
 __device__ __forceinline__ float fract1(float x) { return x - __builtin_floorf(x); }
 __device__ __forceinline__ float clamp01(float x) { return __builtin_fminf(__builtin_fmaxf(x, 0.0f), 1.0f); }
@@ -79,12 +103,22 @@ __device__ __forceinline__ float lp_exp2(float x) {
     return e * __builtin_fmaf(odd, f, even);
 }
 
+// (m - 1) / (m + 1) for a mantissa m in [1, 2): refined reciprocal, quotient, one residual correction -- equal to the IEEE
+// quotient for every one of the 2^23 mantissas (pt_arith_selftest_kernel).
+__device__ __forceinline__ float log2_quotient(float m) {
+    const float num = m - 1.0f, den = m + 1.0f;
+    float r = __builtin_amdgcn_rcpf(den);
+    r = __builtin_fmaf(__builtin_fmaf(-den, r, 1.0f), r, r);
+    const float q = num * r;
+    return __builtin_fmaf(__builtin_fmaf(-den, q, num), r, q);
+}
+
 // log2: exponent + y*P(y^2) with y = (m-1)/(m+1), m the mantissa in [1,2); degree-4 P.
 __device__ __forceinline__ float lp_log2(float x) {
     const uint32_t i = __float_as_uint(x);
     const float e = (float)((int32_t)((i & 0x7f800000u) >> 23) - 127);
     const float m = __uint_as_float((i & 0x007fffffu) | 0x3f800000u);
-    const float y = (m - 1.0f) / (m + 1.0f);
+    const float y = log2_quotient(m);
     const float z = y * y;
     const float z2 = z * z;
     float even = __builtin_fmaf(z2, 0.406718052498846252698f, 0.577440339438736392009f);
@@ -154,7 +188,7 @@ __device__ __forceinline__ void test_triangle(const TriRec& t, int id, v3 rd, Hi
     // fs:142,151. "u <= det" is implied by the other three (v >= 0 makes fl(u+v) >= u), so it is not evaluated.
     const bool inside = (det >= 0.0001f) & (u >= 0.0f) & (v >= 0.0f) & ((u + v) <= det);
     if (inside) {
-        const float ood = 1.0f / det;
+        const float ood = ieee_rcp(det);
         const float tt = t.d.x * ood;
         // The shader visits triangles in ascending id with a strict '<', so among equal distances the lowest id wins.
         // When triangles arrive in another order (BVH leaves) that rule is applied explicitly.
@@ -182,7 +216,7 @@ __device__ __forceinline__ void test_triangle_from(const TriRec& t, int id, v3 r
     const float v = dot3(rd, r);
     const bool inside = (det >= 0.0001f) & (u >= 0.0f) & (v >= 0.0f) & ((u + v) <= det);
     if (inside) {
-        const float ood = 1.0f / det;
+        const float ood = ieee_rcp(det);
         const float tt = dot3(e2, r) * ood;
         const bool closer = ANY_ORDER ? (tt < h.t || (tt == h.t && id < h.id)) : (tt < h.t);
         if (tt > 0.0f && closer) {
@@ -519,7 +553,7 @@ __device__ __forceinline__ Hit intersect_bvh_lanes(const PtKernelParams& p, v3 r
             const float u = dot3(ap, q);
             const float v = dot3(rd, r);
             if ((det >= 0.0001f) & (u >= 0.0f) & (v >= 0.0f) & ((u + v) <= det)) {
-                const float ood = 1.0f / det;
+                const float ood = ieee_rcp(det);
                 const float tt = dot3(e2, r) * ood;
                 const int id = (int)__float_as_uint(rdd.w);
                 if (tt > 0.0f && (tt < h.t || (tt == h.t && id < h.id))) {
@@ -581,7 +615,7 @@ __device__ __forceinline__ Hit intersect_grid(const PtKernelParams& p, v3 rd, un
         const float u = dot3(ap, q);
         const float v = dot3(rd, r);
         if ((det >= 0.0001f) & (u >= 0.0f) & (v >= 0.0f) & ((u + v) <= det)) {
-            const float ood = 1.0f / det;
+            const float ood = ieee_rcp(det);
             const float tt = t.d.x * ood;
             if (tt > 0.0f && (tt < h.t || (tt == h.t && (int)tri < h.id))) {
                 h.t = tt; h.id = (int)tri; h.u = u; h.v = v; h.ood = ood;
@@ -608,7 +642,7 @@ __device__ __forceinline__ Hit intersect_world(const float* __restrict__ sphere_
         const float B = -dot3(V(r0.x, r0.y, r0.z), rd);
         const float disc = B * B - r0.w;
         if (disc > 0.0f) {
-            const float root = __builtin_sqrtf(disc);
+            const float root = ieee_sqrt(disc);
             float temp = B - root;
             temp = temp > 0.0f ? temp : (B + root);
             if (temp > 0.0f && temp < h.t) { h.t = temp; h.id = obj; }
@@ -648,7 +682,7 @@ __device__ __forceinline__ void shade(Rng& rng, float& energy, v3& rd, v3 N) {
     const v3 binormal = normalize3(cross3(R, tangent));
     // randomHemisphere(r1, alpha), fs:67-76
     const float cos_t = lp_pow(r1, 1.0f / (alpha + 1.0f));
-    const float sin_t = __builtin_sqrtf(__builtin_fmaxf(0.0f, 1.0f - cos_t * cos_t));
+    const float sin_t = ieee_sqrt(__builtin_fmaxf(0.0f, 1.0f - cos_t * cos_t));
     const float phi = (rng.rand01() * 2.0f) * 3.141592653589f;
     const v3 hemi = V(lp_sincos<true>(phi) * sin_t, cos_t, lp_sincos<false>(phi) * sin_t);
     // mat3(tangent, R, binormal) * hemi = (c0*x + c1*y) + c2*z
@@ -679,7 +713,7 @@ __device__ __forceinline__ void shade_materials(Rng& rng, const float* __restric
     const v3 tangent = normalize3(cross3(N, helper));
     const v3 binormal = normalize3(cross3(N, tangent));
     const float cos_t = lp_pow(r1, 1.0f / (1.0f + 1.0f));
-    const float sin_t = __builtin_sqrtf(__builtin_fmaxf(0.0f, 1.0f - cos_t * cos_t));
+    const float sin_t = ieee_sqrt(__builtin_fmaxf(0.0f, 1.0f - cos_t * cos_t));
     const float phi = (rng.rand01() * 2.0f) * 3.141592653589f;
     const v3 hemi = V(lp_sincos<true>(phi) * sin_t, cos_t, lp_sincos<false>(phi) * sin_t);
     rd = (tangent * hemi.x + N * hemi.y) + binormal * hemi.z;
@@ -863,7 +897,7 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
             if (scratch_slot >= 0) {
                 scratch[(size_t)(sample_count - remaining) * PT_TILE_THREADS] = make_float4(sr, sg, sb, 0.f);
             } else if (p.accum_mode == 0) {
-                const float a = 1.0f / rng.samples;
+                const float a = ieee_rcp(rng.samples);
                 mr = mr + a * (sr - mr);
                 mg = mg + a * (sg - mg);
                 mb = mb + a * (sb - mb);
@@ -927,6 +961,26 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_primary_kernel(const PtKer
     if (!in_window) return;
     if (p.out_ids) p.out_ids[pix] = h.id;
     if (p.out_t) p.out_t[pix] = h.t;
+}
+
+// The short reciprocal, square-root and log2-quotient sequences against the compiler's IEEE division and square root, for
+// every float bit pattern: bad[0] reciprocal, bad[1] square root, bad[2] quotient -- inputs whose results differ in any
+// bit (NaN payloads included). All three must stay 0.
+__global__ __launch_bounds__(256) void pt_arith_selftest_kernel(unsigned long long* __restrict__ bad) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned b0 = 0, b1 = 0, b2 = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32); i += stride) {
+        const float x = __uint_as_float((uint32_t)i);
+        b0 += __float_as_uint(ieee_rcp(x)) != __float_as_uint(1.0f / x);
+        b1 += __float_as_uint(ieee_sqrt(x)) != __float_as_uint(__builtin_sqrtf(x));
+        if (i < (1ull << 23)) {
+            const float m = __uint_as_float((uint32_t)i | 0x3f800000u);
+            b2 += __float_as_uint(log2_quotient(m)) != __float_as_uint((m - 1.0f) / (m + 1.0f));
+        }
+    }
+    if (b0) atomicAdd(&bad[0], (unsigned long long)b0);
+    if (b1) atomicAdd(&bad[1], (unsigned long long)b1);
+    if (b2) atomicAdd(&bad[2], (unsigned long long)b2);
 }
 
 // One thread per triangle: gathers the three vertices through the index buffer and writes the SoA records.
@@ -1213,6 +1267,11 @@ hipError_t pt_launch_present(const float* img, size_t num_pixels, uint32_t* out_
     const size_t blocks = (num_pixels + 255) / 256;
     hipLaunchKernelGGL(pt_present_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, stream,
                        reinterpret_cast<const float4*>(img), num_pixels, out_rgba8);
+    return hipGetLastError();
+}
+
+hipError_t pt_launch_arith_selftest(unsigned long long* bad, hipStream_t stream) {
+    hipLaunchKernelGGL(pt_arith_selftest_kernel, dim3(256 * 16), dim3(256), 0, stream, bad);
     return hipGetLastError();
 }
 

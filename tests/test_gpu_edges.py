@@ -203,3 +203,9 @@ def test_argument_errors(tracer):
     t.dispatch(1 << 24, 1, 1)              # the last representable sample index is fine
     t.finish()
     t.program_destroy(prog)
+
+
+def test_short_arithmetic_sequences_equal_ieee_for_every_input(tracer):
+    """The kernels' 4-instruction reciprocal, unscaled square root and log2 quotient against the compiler's IEEE division and
+    square root: all 2^32 float inputs (2^23 mantissas for the quotient), results compared bit for bit on the device."""
+    assert tracer.selftest_arithmetic() == (0, 0, 0)

@@ -1,4 +1,5 @@
-// Exhaustive check of cheaper correctly-rounded reciprocal / square-root sequences against the compiler's IEEE lowering,
+// Exploratory version of pt_selftest_arithmetic (which checks the product's own inline functions): exhaustive check of
+// cheaper correctly-rounded reciprocal / square-root sequences against the compiler's IEEE lowering,
 // under the product's floating-point flags (denormals flushed, no contraction). Every one of the 2^32 bit patterns is tried.
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fgpu-flush-denormals-to-zero -fno-fast-math tools/rcp_probe.hip -o tools/rcp_probe
 #include <hip/hip_runtime.h>
@@ -19,11 +20,16 @@ __device__ __forceinline__ float rcp_nr2(float x) {
     r = __builtin_fmaf(e, r, r);
     return __builtin_amdgcn_div_fixupf(r, x, 1.0f);
 }
+// the IEEE square root without the compiler's rescaling of tiny inputs (those take the compiler's own sequence)
 __device__ __forceinline__ float sqrt_nr(float x) {
-    // s ~ sqrt(x) from rsq, one coupled refinement, final residual correction
+    const uint32_t xb = __float_as_uint(x);  // the short way serves +-0 and [2^-96, +inf] and NaN; the rest (tiny, negative) is rare
+    if ((xb - 0x0f800000u) >= 0x70800000u && (xb << 1) != 0u) return __builtin_sqrtf(x);
     const float r = __builtin_amdgcn_rsqf(x);
     float s = x * r;
-    const float h = 0.5f * r;
+    float h = 0.5f * r;
+    const float e = __builtin_fmaf(-h, s, 0.5f);
+    s = __builtin_fmaf(s, e, s);
+    h = __builtin_fmaf(h, e, h);
     const float d = __builtin_fmaf(-s, s, x);
     s = __builtin_fmaf(d, h, s);
     return (x == 0.0f || x == __builtin_inff()) ? x : s;
