@@ -274,12 +274,12 @@ def main():
                                        "latency-bound pointer chasing served by L2/Infinity Cache, far below the HBM roof"}
         if large:
             out["large_scene"] = large
-        # HBM bytes per launch from rocprofv3 PMC passes of this same workload (profiles/r01_pmc_cornell_grid.json:
-        # FETCH_SIZE 18270.9 KB doubled as the gfx950 correction prescribes, plus WRITE_SIZE 348350.6 KB, of which 33 MB are
+        # HBM bytes per launch from rocprofv3 PMC passes of this same workload (profiles/r01_pmc_cornell_grid_v2.json:
+        # FETCH_SIZE 21304.25 KB doubled as the gfx950 correction prescribes, plus WRITE_SIZE 359099.9 KB, of which 33 MB are
         # the image and the rest the parked samples of split tiles); counters cannot be read from inside this run
         if args.workload == "cornell" and (W, H, spp) == (1920, 1080, 256):
-            out["roofline"]["traffic"] = 37418880.0 + 356711040.0
-            out["roofline"]["valu_issue_busy"] = 0.73
+            out["roofline"]["traffic"] = 2 * 21304.25 * 1024 + 359099.875 * 1024
+            out["roofline"]["valu_issue_busy"] = 0.74
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, spp)
         print(json.dumps(out), flush=True)
