@@ -575,11 +575,13 @@ __device__ __forceinline__ Hit intersect_grid(const PtKernelParams& p, v3 rd, un
     Hit h;
     h.t = 1.0e38f; h.id = -1; h.u = 0.f; h.v = 0.f; h.ood = 0.f;
     const float ax = __builtin_fabsf(rd.x), ay = __builtin_fabsf(rd.y), az = __builtin_fabsf(rd.z);
-    int face;
-    float fu, fv, fw;
-    if (ax >= ay && ax >= az) { face = rd.x < 0.f ? 1 : 0; fu = rd.y; fv = rd.z; fw = ax; }
-    else if (ay >= az) { face = rd.y < 0.f ? 3 : 2; fu = rd.z; fv = rd.x; fw = ay; }
-    else { face = rd.z < 0.f ? 5 : 4; fu = rd.x; fv = rd.y; fw = az; }
+    // major axis by selects (no branches: the three cases are spread evenly over the lanes of a wave)
+    const bool xmaj = ax >= ay && ax >= az, ymaj = !xmaj && ay >= az;
+    const float major = xmaj ? rd.x : (ymaj ? rd.y : rd.z);
+    const float fu = xmaj ? rd.y : (ymaj ? rd.z : rd.x);
+    const float fv = xmaj ? rd.z : (ymaj ? rd.x : rd.y);
+    const float fw = __builtin_fabsf(major);
+    const int face = (xmaj ? 0 : (ymaj ? 2 : 4)) + (major < 0.f ? 1 : 0);
     if (!(fw > 0.f)) return h;  // a zero or NaN direction hits nothing
     const float iw = __builtin_amdgcn_rcpf(fw);
     const int res = p.grid_res;

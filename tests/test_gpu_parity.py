@@ -477,3 +477,37 @@ def test_c1_full_size_against_llvmpipe_digests(tracer):
         t.finish()
         assert digest() == gold["sha256"]["16"]
     t.program_destroy(prog)
+
+
+def test_c2_benchmark_configuration_against_llvmpipe_digests(tracer):
+    """The benchmark workload itself (cornell_box.obj, 1920x1080, passes 1..256, what bench.py times): SHA-256 digests of the
+    RGBA32F image the reference shader produced on llvmpipe after 1, 16, 64 and 256 passes (oracle/time_c1.py --c2). The
+    device image must hash to the same bytes when the passes are dispatched in four ranges, and when all 256 samples are one
+    dispatch as in the benchmark (twice: the second time from a work list with split tiles)."""
+    import hashlib
+    import json
+    import os
+    from helpers import GOLDEN
+    from pathtracer_amd.scenes import SceneData
+    gold = json.load(open(os.path.join(GOLDEN, "c2_cornell_1080p.json")))
+    scene = SceneData("cornell")
+    assert (scene.width, scene.height) == (1920, 1080)
+    assert n_bit_mismatch(scene.camera, np.asarray(gold["camera"], np.float32)) == 0
+    t = tracer
+    prog = scene.upload(t)
+    t.set_accel_mode(0)
+    t.set_accum_mode(0)
+    t.target_create(1920, 1080)
+    digest = lambda: hashlib.sha256(t.readback().tobytes()).hexdigest()
+    done = 0
+    for k in (1, 16, 64, 256):
+        t.dispatch(done + 1, k - done, 1)
+        t.finish()
+        done = k
+        assert digest() == gold["sha256"][str(k)], f"after {k} passes"
+    for _ in range(2):
+        t.target_clear()
+        t.dispatch(1, 256, 1)
+        t.finish()
+        assert digest() == gold["sha256"]["256"]
+    t.program_destroy(prog)
