@@ -280,6 +280,14 @@ def main():
         if args.workload == "cornell" and (W, H, spp) == (1920, 1080, 256):
             out["roofline"]["traffic"] = 2 * 21304.25 * 1024 + 359099.875 * 1024
             out["roofline"]["valu_issue_busy"] = 0.74
+        # the reference shader itself on Mesa llvmpipe, same scene, camera and passes: recorded in the build container (the
+        # shader text does not travel to the GPU box), see oracle/time_c1.py --c2
+        gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "c2_cornell_1080p.json")
+        if args.workload == "cornell" and (W, H, spp) == (1920, 1080, 256) and os.path.exists(gold):
+            lp = json.load(open(gold))["llvmpipe"]
+            out["llvmpipe_recorded"] = {"Mrays_per_s": lp["Mrays_per_s"], "ms_per_pass_median": lp["pass_ms_median"], "cores": lp["threads"],
+                                        "renderer": lp["renderer"], "note": "reference pathtracing.fs, passes 1..256 of this workload, timed around glDrawArrays..glFinish "
+                                        "in the build container, not on this machine; its final image is bit-identical to this run's (tests/golden/c2_cornell_1080p.json)"}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, spp)
         print(json.dumps(out), flush=True)
