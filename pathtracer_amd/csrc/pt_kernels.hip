@@ -616,6 +616,9 @@ __device__ __forceinline__ Hit intersect_grid(const PtKernelParams& p, v3 rd, un
         const v3 r = V(t.c.y, t.c.z, t.c.w);
         const float u = dot3(ap, q);
         const float v = dot3(rd, r);
+        // the record's last quarter (e2r, normal) is only used by a hit; without this the compiler fetches it inside the
+        // two branches below, two more round trips in a row -- here it arrives together with the other three quarters
+        asm volatile("" : "+v"(t.d.x), "+v"(t.d.y), "+v"(t.d.z), "+v"(t.d.w));
         if ((det >= 0.0001f) & (u >= 0.0f) & (v >= 0.0f) & ((u + v) <= det)) {
             const float ood = ieee_rcp(det);
             const float tt = t.d.x * ood;
