@@ -499,7 +499,7 @@ PtStatus pt_create(int32_t device, PtContext** out_ctx) {
     else if (sched && sched[0] == 't') ctx->sched_mode = 1;
     ctx->wave_slots = prop.multiProcessorCount * 4 * 8;
     if (const char* g = getenv("PT_AUTO_GRID")) ctx->auto_grid = g[0] != '0';
-    if (const char* g = getenv("PT_GRID_RES")) ctx->grid_res_override = atoi(g);
+    if (const char* g = getenv("PT_GRID_RES")) ctx->grid_res_override = std::min(atoi(g), 8192);  // cell indices stay far below 2^32
     if (const char* l = getenv("PT_LANE_WALK")) ctx->lane_walk = l[0] != '0';
     if (const char* l = getenv("PT_LANE_STACK_LIMIT")) ctx->lane_stack_limit = std::max(0, std::min(PT_LANE_STACK, atoi(l)));
     if (const char* k = getenv("PT_KEEP_UNREACHABLE")) ctx->keep_unreachable = k[0] == '1';

@@ -589,7 +589,8 @@ __device__ __forceinline__ Hit intersect_grid(const PtKernelParams& p, v3 rd, un
     int iu = (int)__builtin_floorf((fu * iw + 1.0f) * half), iv = (int)__builtin_floorf((fv * iw + 1.0f) * half);
     iu = iu < 0 ? 0 : (iu >= res ? res - 1 : iu);
     iv = iv < 0 ? 0 : (iv >= res ? res - 1 : iv);
-    const uint32_t cell = ((uint32_t)face * (uint32_t)res + (uint32_t)iv) * (uint32_t)res + (uint32_t)iu;  // < 6 * 2048^2
+    // < 6 * 2048^2; both factors of either product are below 2^24, so the full-rate 24-bit multiply is exact
+    const uint32_t cell = __umul24(__umul24((uint32_t)face, (uint32_t)res) + (uint32_t)iv, (uint32_t)res) + (uint32_t)iu;
     // One word per cell: empty, the cell's only triangle (then the record is the very next fetch), or the position of its
     // list, whose last entry carries the top bit.
     uint32_t entry = p.grid_cells[cell];
