@@ -73,6 +73,7 @@ struct PtBvhBuild {
 // Direction grid (pt_grid.hip): for rays that all start at the camera, cube-map cells -> triangles a direction of the
 // cell could hit.
 #define PT_GRID_EMPTY 0xffffffffu
+#define PT_PROBE_SAMPLES 8  // samples a long dispatch without tile costs renders first, to have costs for the rest
 struct PtGridBuild {
     int32_t res;
     uint32_t* cell_count;   // 6*res*res + 1: counts during the build, fill cursors afterwards

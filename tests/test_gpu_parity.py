@@ -511,3 +511,44 @@ def test_c2_benchmark_configuration_against_llvmpipe_digests(tracer):
         t.finish()
         assert digest() == gold["sha256"]["256"]
     t.program_destroy(prog)
+
+
+def test_long_first_dispatch_probes_then_schedules():
+    """A long dispatch that has no tile costs to go by (new context; later: new camera position) renders its first samples on
+    their own and schedules the rest from their costs. Same image as the llvmpipe digest / as frame-by-frame dispatches, and
+    it still counts as one dispatch."""
+    import hashlib
+    import json
+    import os
+    from helpers import GOLDEN
+    from pathtracer_amd import Tracer
+    from pathtracer_amd.scenes import SceneData
+    gold = json.load(open(os.path.join(GOLDEN, "c2_cornell_1080p.json")))
+    scene = SceneData("cornell")
+    t = Tracer(0)
+    try:
+        scene.upload(t)
+        t.set_accum_mode(0)
+        t.target_create(1920, 1080)
+        t.dispatch(1, 256, 1)
+        t.finish()
+        assert hashlib.sha256(t.readback().tobytes()).hexdigest() == gold["sha256"]["256"]
+        assert t.stats()["dispatches"] == 1
+        assert t.stats()["samples"] == 1920 * 1080 * 256
+        # another camera position: the costs are stale, the next long dispatch probes again
+        small = SceneData("cornell", 320, 200)
+        cam = small.camera.copy()
+        cam[0] += 40.0
+        cam[3] += 40.0  # eye and lower-left corner moved together
+        t.target_create(320, 200)
+        t.set_uniforms(cam, small.num_triangles, 10)
+        t.dispatch(1, 64, 1)
+        t.finish()
+        whole = t.readback()
+        t.target_clear()
+        for s in range(1, 65):
+            t.dispatch(s, 1, 1)
+        t.finish()
+        assert n_bit_mismatch(whole, t.readback()) == 0
+    finally:
+        t.close()

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--lib", default=None)
     ap.add_argument("--accel", default="auto", choices=["auto", "brute", "bvh", "cull", "grid"])
     ap.add_argument("--shading", default="reference", choices=["reference", "materials"])
+    ap.add_argument("--cold", action="store_true", help="no warm-up dispatch: the first timed dispatch has no tile costs to go by")
     ap.add_argument("--no-reuse", action="store_true", help="evaluate the camera ray for every sample, like the shader")
     args = ap.parse_args()
     from pathtracer_amd import Tracer
@@ -39,8 +40,9 @@ def main():
         t.set_accel_mode({"brute": 1, "cull": 3, "auto": 0, "grid": 4}[args.accel])
     t.set_primary_reuse(not args.no_reuse)
     t.enable_timing(True)
-    t.dispatch(1, 1, 1)
-    t.finish()
+    if not args.cold:
+        t.dispatch(1, 1, 1)
+        t.finish()
     t.reset_stats()
     per_rep = []
     for _ in range(args.reps):
