@@ -862,6 +862,34 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
     float pend_t = t0;
     int pend_id = id0;
 
+    // A wave none of whose pixels sees the scene (most waves of a sparse view): every sample of such a pixel ends at its
+    // camera ray with the same sky colour (fs:408-410 with energy 1), so the samples are folded in a short loop here
+    // instead of one trip of the big loop each. Once the running mean equals that colour, further folds leave it as it
+    // is (x + a * (y - x) with y - x = 0), so the loop stops there.
+    if (reuse && __builtin_amdgcn_ballot_w64(hit0 && remaining > 0) == 0ull) {
+        if (remaining > 0) {
+            const float t = 0.5f * (rd0.y + 1.0f);
+            const float omt = 1.0f - t;
+            const float sr = omt + 0.5f * t, sg = omt + 0.7f * t, sb = omt + 1.0f * t;
+            rays += (unsigned)(remaining - 1);  // one camera-ray query per sample; the first is already counted
+            for (int k = 0; k < sample_count; ++k) {
+                if (scratch_slot >= 0) {
+                    scratch[(size_t)k * PT_TILE_THREADS] = make_float4(sr, sg, sb, 0.f);
+                } else if (p.accum_mode == 0) {
+                    if (mr == sr && mg == sg && mb == sb) break;
+                    const float a = ieee_rcp((float)sample);
+                    mr = mr + a * (sr - mr);
+                    mg = mg + a * (sg - mg);
+                    mb = mb + a * (sb - mb);
+                } else {
+                    mr += sr; mg += sg; mb += sb;
+                }
+                sample += p.sample_stride;
+            }
+            remaining = 0;
+        }
+    }
+
     // One loop trip = [shade the pending hit, Shade() fs:224-361] then [closest hit of the new direction]; a sample that
     // ends (miss, throughput 0, depth reached: fs:388,402) is folded into the pixel and the lane starts its next sample
     // in the same trip, so lanes of a wave stay busy although their paths differ in length.
