@@ -1208,7 +1208,9 @@ __global__ __launch_bounds__(1024) void pt_schedule_items_kernel(uint32_t* __res
     if (threadIdx.x < 64) hist[threadIdx.x] = 0;
     if (threadIdx.x == 0) { total = 0; num_split = 0; }
     __syncthreads();
+    // One workgroup walks all tiles several times; each thread fetches the costs of four of its tiles at once.
     unsigned long long mine = 0;
+#pragma unroll 4
     for (int i = threadIdx.x; i < n; i += blockDim.x) mine += cost[i];
     atomicAdd(&total, mine);
     __syncthreads();
@@ -1223,16 +1225,28 @@ __global__ __launch_bounds__(1024) void pt_schedule_items_kernel(uint32_t* __res
     };
     // pieces of a tile and samples per piece
     auto split = [granule, num_samples](uint32_t c, int& per_piece) -> int {
+        if ((unsigned long long)c <= granule) {  // the usual tile: one item (and none of the divisions below, which are long
+            per_piece = num_samples;             // instruction sequences that one workgroup would run for every tile)
+            return 1;
+        }
         unsigned long long k = ((unsigned long long)c + granule - 1) / granule;
         if (k < 1) k = 1;
         if (k > (unsigned long long)num_samples) k = (unsigned long long)num_samples;
         per_piece = (num_samples + (int)k - 1) / (int)k;
         return (num_samples + per_piece - 1) / per_piece;
     };
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        int per_piece;
-        const int k = split(cost[i], per_piece);
-        atomicAdd(&hist[bucket(cost[i] / (uint32_t)k)], (uint32_t)k);
+    const int step4 = 4 * (int)blockDim.x;
+    for (int i0 = threadIdx.x; i0 < n; i0 += step4) {
+        uint32_t c[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int i = i0 + j * (int)blockDim.x; c[j] = i < n ? cost[i] : 0u; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (i0 + j * (int)blockDim.x >= n) break;
+            int per_piece;
+            const int k = split(c[j], per_piece);
+            atomicAdd(&hist[bucket(c[j] / (uint32_t)k)], (uint32_t)k);
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1241,10 +1255,17 @@ __global__ __launch_bounds__(1024) void pt_schedule_items_kernel(uint32_t* __res
         counts[0] = acc;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    for (int i0 = threadIdx.x; i0 < n; i0 += step4) {
+      uint32_t c[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const int i = i0 + j * (int)blockDim.x; c[j] = i < n ? cost[i] : 0u; }
+#pragma unroll
+      for (int j4 = 0; j4 < 4; ++j4) {
+        const int i = i0 + j4 * (int)blockDim.x;
+        if (i >= n) break;
         int per_piece;
-        const int k = split(cost[i], per_piece);
-        const uint32_t first = atomicAdd(&start[bucket(cost[i] / (uint32_t)k)], (uint32_t)k);
+        const int k = split(c[j4], per_piece);
+        const uint32_t first = atomicAdd(&start[bucket(c[j4] / (uint32_t)k)], (uint32_t)k);
         int slot = -1;
         if (k > 1) {
             slot = (int)atomicAdd(&num_split, 1u);
@@ -1258,6 +1279,7 @@ __global__ __launch_bounds__(1024) void pt_schedule_items_kernel(uint32_t* __res
             it.scratch_slot = slot;
             items[first + (uint32_t)j] = it;
         }
+      }
     }
     __syncthreads();
     if (threadIdx.x == 0) counts[1] = num_split;
