@@ -866,6 +866,7 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
     // camera ray with the same sky colour (fs:408-410 with energy 1), so the samples are folded in a short loop here
     // instead of one trip of the big loop each. Once the running mean equals that colour, further folds leave it as it
     // is (x + a * (y - x) with y - x = 0), so the loop stops there.
+#ifndef PT_V_NO_SKY
     if (reuse && __builtin_amdgcn_ballot_w64(hit0 && remaining > 0) == 0ull) {
         if (remaining > 0) {
             const float t = 0.5f * (rd0.y + 1.0f);
@@ -889,6 +890,7 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
             remaining = 0;
         }
     }
+#endif
 
     // One loop trip = [shade the pending hit, Shade() fs:224-361] then [closest hit of the new direction]; a sample that
     // ends (miss, throughput 0, depth reached: fs:388,402) is folded into the pixel and the lane starts its next sample

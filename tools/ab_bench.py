@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 VARIANTS = {
     "base": [],
     "vfirst": ["-DPT_V_VFIRST"],
-    "cur": [],
+    "nosky": ["-DPT_V_NO_SKY"],
 }
 
 
