@@ -117,10 +117,13 @@ struct PtContext {
     bool keep_unreachable = false;        // PT_KEEP_UNREACHABLE=1: the loop walks all records (to measure the compaction)
     int32_t sched_win[4] = {-1, -1, -1, -1};  // window the costs were measured for
     bool sched_have_cost = false;
+    float list_base_factor = -1.f;        // the list was built for this split factor (before the automatic step to the eager one)
+    int list_items = 0, list_split = 0;   // what the scheduler produced: items and split tiles (launch sizes)
+    bool concentrated = false;            // the work of this view sits in few tiles: lists are built with the eager split factor
     bool costs_stale = false;             // the tile costs were gathered for another mesh or camera position
     // the work list built last and what it was built for; reused while nothing it depends on changes
     bool list_valid = false;
-    int32_t list_samples = 0, list_max_split = 0, list_age = 0;
+    int32_t list_samples = 0, list_age = 0;
     int64_t cost_samples = 0;   // samples per pixel behind the costs gathered since the list was built
     int64_t list_basis = 0;     // samples per pixel behind the costs the list was built from
     int sched_mode = 2;             // 0 raster order, 1 cost-ordered tiles, 2 cost-ordered items with heavy tiles split by samples
@@ -848,50 +851,68 @@ PtStatus dispatch_range(PtContext* ctx, int32_t first_sample, int32_t num_sample
         const int tiles = PT_TILES_ACROSS(ctx->win[2]) * PT_TILES_ACROSS(ctx->win[3]);
         const bool same_window = memcmp(ctx->sched_win, ctx->win, sizeof ctx->win) == 0;
         if (ctx->sched_have_cost && same_window) {
-            // Split tiles park their samples in scratch memory: max_split slots of num_samples x tile pixels x 16 bytes,
-            // grown on demand and capped at 8 GiB (fewer splits beyond that).
-            // How eagerly tiles are split (a tile is split when its cost exceeds total / (factor x wave slots)): the
-            // all-triangles loop is throughput-bound and every extra block adds a drain phase in which lanes idle, so only
-            // tiles longer than the whole balanced kernel are split (measured on the 36-triangle scene: factor 0: 30.9 ms,
-            // 1: 31.0, 2: 31.5, 4: 31.9); the hierarchy walk is latency-bound and gains from every additional wave
-            // (968 triangles: 8.7 ms unsplit, 3.1 at factor 1, 2.6 at factor 4).
-            float factor = (p.bvh_nodes || p.bvh_nodes_abs) ? 4.0f : 1.0f;  // direction grid, 1080p Cornell: 9.6 ms at 0 and 1, 10.1 at 2, 10.6 at 4;
-                                                                            // suzanne 0.87 / 0.54 / 0.50 / 0.51
-            if (ctx->split_factor >= 0.f) factor = ctx->split_factor < (float)PT_MAX_SPLIT_FACTOR ? ctx->split_factor : (float)PT_MAX_SPLIT_FACTOR;
-            int max_split = (ctx->sched_mode == 2 && num_samples > 1) ? (int)(factor * (float)ctx->wave_slots) : 0;
-            const size_t slot_bytes = (size_t)num_samples * PT_TILE_THREADS * 16;
-            const size_t cap = (size_t)8 << 30;
-            if (max_split > 0 && slot_bytes * (size_t)max_split > cap) max_split = (int)(cap / slot_bytes);
-            if (max_split > 0 && slot_bytes * (size_t)max_split > ctx->sample_scratch_bytes) {
-                PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
-                if (ctx->d_sample_scratch) (void)hipFree(ctx->d_sample_scratch);
-                ctx->d_sample_scratch = nullptr;
-                ctx->sample_scratch_bytes = 0;
-                PT_HIP_TRY(hipMalloc(&ctx->d_sample_scratch, slot_bytes * (size_t)max_split));
-                ctx->sample_scratch_bytes = slot_bytes * (size_t)max_split;
-            }
             // The list stays valid for any later dispatch of the same window and sample count (it only has to cover
             // every tile and sample once), so a frame loop does not pay for the scheduler on every frame. It is rebuilt
             // after scene or camera changes, every 16th dispatch, and as soon as the costs gathered since rest on twice as
             // many samples as the ones it was built from: one sample per pixel is a noisy estimate of a tile's cost, and
             // a list built from it left the truly long tiles unsplit (1M triangles, 16 spp: 11.0 ms against 7.6 ms with
             // costs from 16 samples).
-            const bool reuse = ctx->list_valid && ctx->list_samples == num_samples && ctx->list_max_split == max_split &&
+            // How eagerly tiles are split (a tile is split when its cost exceeds total / (factor x wave slots)): the
+            // hierarchy walk is latency-bound and gains from every additional wave (968 triangles: 8.7 ms unsplit, 3.1 at
+            // factor 1, 2.6 at factor 4). The loop and the direction grid are throughput-bound, every extra block adds a
+            // drain phase and scratch traffic, so a view whose work is spread over more tiles than the device holds waves
+            // is best left alone (1080p Cornell: 8.2 ms at factor 1, 8.7 at 2, 9.5 at 4; 1M triangles at 4K: 2.0 / 2.1 /
+            // 2.6). A view whose work sits in few tiles is different: when the factor-1 list already splits a fifth of
+            // the wave slots' worth of tiles, the largest factor is used from then on (968 triangles: 1.19 -> 0.96 ms,
+            // 3,936: 2.22 -> 1.94, the sphere scene 0.71 -> 0.65), until the costs are dropped (new view).
+            const float base_factor = ctx->split_factor >= 0.f ? std::min(ctx->split_factor, (float)PT_MAX_SPLIT_FACTOR)
+                                                               : ((p.bvh_nodes || p.bvh_nodes_abs) ? 4.0f : 1.0f);
+            const bool splitting = ctx->sched_mode == 2 && num_samples > 1;
+            const size_t slot_bytes = (size_t)num_samples * PT_TILE_THREADS * 16;
+            const bool reuse = ctx->list_valid && ctx->list_samples == num_samples && ctx->list_base_factor == base_factor &&
                                ctx->list_age < 16 && ctx->cost_samples < 2 * ctx->list_basis;
             if (!reuse) {
-                PT_HIP_TRY(pt_launch_schedule_items(ctx->d_tile_cost, ctx->d_items, ctx->d_sched_counts, ctx->d_split_tiles, tiles, num_samples,
-                                                    max_split, ctx->stream));
+                // The scheduler's counts are read back (a short stall, at rebuilds only): they size the launches and the
+                // scratch exactly, and they tell whether this view wants the eager split.
+                float factor = (ctx->concentrated && ctx->split_factor < 0.f) ? (float)PT_MAX_SPLIT_FACTOR : base_factor;
+                uint32_t c[2] = {0, 0};
+                for (;;) {
+                    const int max_split = splitting ? (int)(factor * (float)ctx->wave_slots) : 0;
+                    PT_HIP_TRY(pt_launch_schedule_items(ctx->d_tile_cost, ctx->d_items, ctx->d_sched_counts, ctx->d_split_tiles, tiles,
+                                                        num_samples, max_split, ctx->stream));
+                    PT_HIP_TRY(hipMemcpyAsync(c, ctx->d_sched_counts, sizeof c, hipMemcpyDeviceToHost, ctx->stream));
+                    PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
+                    if (getenv("PT_DEBUG_SCHED"))
+                        fprintf(stderr, "[pt sched] %d tiles, %d samples, costs from %lld samples, factor %g: %u items, %u split tiles\n", tiles,
+                                num_samples, (long long)ctx->cost_samples, (double)factor, c[0], c[1]);
+                    if (!splitting) break;
+                    if (ctx->split_factor < 0.f && factor == 1.0f && c[1] >= (uint32_t)(ctx->wave_slots / 5)) {
+                        factor = (float)PT_MAX_SPLIT_FACTOR;  // work concentrated in few tiles
+                        ctx->concentrated = true;
+                        continue;
+                    }
+                    if ((size_t)c[1] * slot_bytes > ((size_t)8 << 30) && factor > 0.f) {  // scratch capped at 8 GiB: split less
+                        factor = factor > 0.26f ? factor * 0.5f : 0.f;
+                        continue;
+                    }
+                    break;
+                }
+                PT_HIP_TRY(hipMemsetAsync(ctx->d_tile_cost, 0, (size_t)tiles * sizeof(uint32_t), ctx->stream));
+                // split tiles park their samples in scratch memory: 16 bytes per pixel and sample
+                const size_t need = (size_t)c[1] * slot_bytes;
+                if (need > ctx->sample_scratch_bytes) {
+                    if (ctx->d_sample_scratch) (void)hipFree(ctx->d_sample_scratch);
+                    ctx->d_sample_scratch = nullptr;
+                    ctx->sample_scratch_bytes = 0;
+                    PT_HIP_TRY(hipMalloc(&ctx->d_sample_scratch, need + need / 8));
+                    ctx->sample_scratch_bytes = need + need / 8;
+                }
                 ctx->list_valid = true;
                 ctx->list_samples = num_samples;
-                ctx->list_max_split = max_split;
+                ctx->list_base_factor = base_factor;
+                ctx->list_items = (int)c[0];
+                ctx->list_split = (int)c[1];
                 ctx->list_age = 0;
-                if (getenv("PT_DEBUG_SCHED")) {  // what the scheduler decided (diagnostics; synchronises)
-                    uint32_t c[2] = {0, 0};
-                    (void)hipMemcpyAsync(c, ctx->d_sched_counts, sizeof c, hipMemcpyDeviceToHost, ctx->stream);
-                    (void)hipStreamSynchronize(ctx->stream);
-                    fprintf(stderr, "[pt sched] %d tiles, %d samples, costs from %lld samples: %u items, %u split tiles (limit %d)\n", tiles,
-                            num_samples, (long long)ctx->cost_samples, c[0], c[1], max_split);
-                }
                 ctx->list_basis = ctx->cost_samples > 0 ? ctx->cost_samples : 1;
                 ctx->cost_samples = 0;
             }
@@ -900,14 +921,15 @@ PtStatus dispatch_range(PtContext* ctx, int32_t first_sample, int32_t num_sample
             p.sched_counts = ctx->d_sched_counts;
             p.split_tiles = ctx->d_split_tiles;
             p.sample_scratch = ctx->d_sample_scratch;
-            p.max_items = tiles + max_split;
-            p.max_split_tiles = max_split;
+            p.max_items = ctx->list_items;
+            p.max_split_tiles = ctx->list_split;
         } else {
             PT_HIP_TRY(hipMemsetAsync(ctx->d_tile_cost, 0, (size_t)tiles * sizeof(uint32_t), ctx->stream));
             p.items = nullptr;
             ctx->list_valid = false;
             ctx->cost_samples = 0;
             ctx->costs_stale = false;
+            ctx->concentrated = false;
         }
         p.tile_cost = ctx->d_tile_cost;
         ctx->cost_samples += num_samples;

@@ -187,7 +187,8 @@ hipError_t pt_launch_render(const PtKernelParams& p, int program_kind, hipStream
 hipError_t pt_launch_present(const float* img, size_t num_pixels, uint32_t* out_rgba8, hipStream_t stream);
 // Work list for the next dispatch from the per-tile costs of the previous one: tiles whose cost exceeds
 // total / max_split_tiles are split into several items (at most num_samples), items ordered most expensive first.
-// Always: item count <= num_tiles + max_split_tiles and split tiles <= max_split_tiles. tile_cost <- 0.
-hipError_t pt_launch_schedule_items(uint32_t* tile_cost, PtWorkItem* items, uint32_t* sched_counts, uint32_t* split_tiles, int num_tiles,
+// Always: item count <= num_tiles + max_split_tiles and split tiles <= max_split_tiles. tile_cost is only read.
+// sched_counts <- {items, split tiles}.
+hipError_t pt_launch_schedule_items(const uint32_t* tile_cost, PtWorkItem* items, uint32_t* sched_counts, uint32_t* split_tiles, int num_tiles,
                                     int num_samples, int max_split_tiles, hipStream_t stream);
 hipError_t pt_launch_primary(const PtKernelParams& p, int program_kind, hipStream_t stream);

@@ -1200,8 +1200,9 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_fold_samples_kernel(const 
 // granule = total cost / max_split + 1: a tile above it is split into ceil(cost / granule) items of equal sample counts
 // (at most num_samples), so the extra items and the split tiles both stay below max_split. Items are placed most
 // expensive first by half-octave bucket of their cost (a counting sort done by one workgroup; positions inside a bucket
-// are handed out atomically, so the list is always a complete cover). Also clears the costs for the next accumulation.
-__global__ __launch_bounds__(1024) void pt_schedule_items_kernel(uint32_t* __restrict__ cost, PtWorkItem* __restrict__ items,
+// are handed out atomically, so the list is always a complete cover). The costs are left as they are (the caller may run the
+// scheduler again with another limit before clearing them).
+__global__ __launch_bounds__(1024) void pt_schedule_items_kernel(const uint32_t* __restrict__ cost, PtWorkItem* __restrict__ items,
                                                                  uint32_t* __restrict__ counts, uint32_t* __restrict__ split_tiles, int n,
                                                                  int num_samples, int max_split, int sort) {
     __shared__ uint32_t hist[64], start[64];
@@ -1285,7 +1286,6 @@ __global__ __launch_bounds__(1024) void pt_schedule_items_kernel(uint32_t* __res
     }
     __syncthreads();
     if (threadIdx.x == 0) counts[1] = num_split;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) cost[i] = 0;
 }
 
 int window_tiles(const PtKernelParams& p) { return PT_TILES_ACROSS(p.win_w) * PT_TILES_ACROSS(p.win_h); }
@@ -1333,7 +1333,7 @@ hipError_t pt_launch_arith_selftest(unsigned long long* bad, hipStream_t stream)
     return hipGetLastError();
 }
 
-hipError_t pt_launch_schedule_items(uint32_t* tile_cost, PtWorkItem* items, uint32_t* sched_counts, uint32_t* split_tiles, int num_tiles,
+hipError_t pt_launch_schedule_items(const uint32_t* tile_cost, PtWorkItem* items, uint32_t* sched_counts, uint32_t* split_tiles, int num_tiles,
                                     int num_samples, int max_split_tiles, hipStream_t stream) {
     if (num_tiles <= 0) return hipSuccess;
     static const int sort = getenv("PT_SCHED_SORT") ? atoi(getenv("PT_SCHED_SORT")) : 1;
