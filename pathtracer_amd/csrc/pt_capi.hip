@@ -118,6 +118,7 @@ struct PtContext {
     int32_t sched_win[4] = {-1, -1, -1, -1};  // window the costs were measured for
     bool sched_have_cost = false;
     float list_base_factor = -1.f;        // the list was built for this split factor (before the automatic step to the eager one)
+    int list_entry_bytes = 0;             // bytes per parked sample the scratch was sized for
     int list_items = 0, list_split = 0;   // what the scheduler produced: items and split tiles (launch sizes)
     bool concentrated = false;            // the work of this view sits in few tiles: lists are built with the eager split factor
     bool costs_stale = false;             // the tile costs were gathered for another mesh or camera position
@@ -868,9 +869,10 @@ PtStatus dispatch_range(PtContext* ctx, int32_t first_sample, int32_t num_sample
             const float base_factor = ctx->split_factor >= 0.f ? std::min(ctx->split_factor, (float)PT_MAX_SPLIT_FACTOR)
                                                                : ((p.bvh_nodes || p.bvh_nodes_abs) ? 4.0f : 1.0f);
             const bool splitting = ctx->sched_mode == 2 && num_samples > 1;
-            const size_t slot_bytes = (size_t)num_samples * PT_TILE_THREADS * 16;
+            const int entry_bytes = ctx->shading_mode == PT_SHADE_MATERIALS && prog->kind != PT_PROGRAM_WORLD ? 16 : 8;  // what a parked sample takes
+            const size_t slot_bytes = (size_t)num_samples * PT_TILE_THREADS * (size_t)entry_bytes;
             const bool reuse = ctx->list_valid && ctx->list_samples == num_samples && ctx->list_base_factor == base_factor &&
-                               ctx->list_age < 16 && ctx->cost_samples < 2 * ctx->list_basis;
+                               ctx->list_entry_bytes == entry_bytes && ctx->list_age < 16 && ctx->cost_samples < 2 * ctx->list_basis;
             if (!reuse) {
                 // The scheduler's counts are read back (a short stall, at rebuilds only): they size the launches and the
                 // scratch exactly, and they tell whether this view wants the eager split.
@@ -898,7 +900,7 @@ PtStatus dispatch_range(PtContext* ctx, int32_t first_sample, int32_t num_sample
                     break;
                 }
                 PT_HIP_TRY(hipMemsetAsync(ctx->d_tile_cost, 0, (size_t)tiles * sizeof(uint32_t), ctx->stream));
-                // split tiles park their samples in scratch memory: 16 bytes per pixel and sample
+                // split tiles park their samples in scratch memory: 8 (materials mode 16) bytes per pixel and sample
                 const size_t need = (size_t)c[1] * slot_bytes;
                 if (need > ctx->sample_scratch_bytes) {
                     if (ctx->d_sample_scratch) (void)hipFree(ctx->d_sample_scratch);
@@ -910,6 +912,7 @@ PtStatus dispatch_range(PtContext* ctx, int32_t first_sample, int32_t num_sample
                 ctx->list_valid = true;
                 ctx->list_samples = num_samples;
                 ctx->list_base_factor = base_factor;
+                ctx->list_entry_bytes = entry_bytes;
                 ctx->list_items = (int)c[0];
                 ctx->list_split = (int)c[1];
                 ctx->list_age = 0;

@@ -165,7 +165,8 @@ struct PtKernelParams {
     const PtWorkItem* items;            // work list (block -> item), or null = block b renders tile b with all samples
     const uint32_t* sched_counts;       // [0] number of items, [1] number of split tiles (device scalars written by the scheduler)
     const uint32_t* split_tiles;        // scratch slot -> tile
-    float* sample_scratch;              // slots x num_samples x 64 lanes x (r, g, b, -): samples of split tiles, folded afterwards
+    float* sample_scratch;              // slots x num_samples x 64 lanes x (throughput, direction y | materials mode: r, g, b, -):
+                                        // samples of split tiles, folded afterwards
     int32_t max_items, max_split_tiles; // launch sizes (upper bounds of the two counts)
     uint32_t* tile_cost;                // per tile: loop trips spent on it in this dispatch (scheduling hint), or null
     int32_t* out_ids;                   // primary pass only

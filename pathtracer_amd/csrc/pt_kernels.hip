@@ -764,6 +764,9 @@ __device__ __forceinline__ unsigned __reduce_max_trips(unsigned v) {
     return v;
 }
 
+__device__ __forceinline__ void park(float2* e, float, float, float, float energy, float rdy) { *e = make_float2(energy, rdy); }
+__device__ __forceinline__ void park(float4* e, float sr, float sg, float sb, float, float) { *e = make_float4(sr, sg, sb, 0.f); }
+
 // KIND: 0 sphere scene, 1 all-triangles loop, 2 LBVH, 3 culled loop. MATERIALS: false = the reference's shading (Phong
 // lobe, grey throughput, origin fixed at the camera), true = the diffuse/emissive mode (coloured throughput, emitted
 // radiance, origin moves to each hit point, so the ray-origin-specific triangle records cannot be used).
@@ -794,9 +797,13 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
     float4 prev = make_float4(0.f, 0.f, 0.f, 1.f);
     if (in_window && scratch_slot < 0) prev = reinterpret_cast<const float4*>(p.src)[pix];
     float mr = prev.x, mg = prev.y, mb = prev.z;
-    float4* __restrict__ scratch = nullptr;
+    // what a parked sample is: the reference shading's three channels are functions of the throughput and the final
+    // direction's y (fs:408-410), so those two are kept (8 bytes) and pt_fold_samples_kernel forms the channels with the same
+    // operations; the materials mode keeps the channels themselves (16 bytes)
+    using Parked = typename std::conditional<MATERIALS, float4, float2>::type;
+    Parked* __restrict__ scratch = nullptr;
     if (scratch_slot >= 0)
-        scratch = reinterpret_cast<float4*>(p.sample_scratch) + ((size_t)scratch_slot * p.num_samples + sample_begin) * PT_TILE_THREADS + threadIdx.x;
+        scratch = reinterpret_cast<Parked*>(p.sample_scratch) + ((size_t)scratch_slot * p.num_samples + sample_begin) * PT_TILE_THREADS + threadIdx.x;
 
     int remaining = in_window ? sample_count : 0;
     int sample = p.first_sample + sample_begin * p.sample_stride;
@@ -875,7 +882,7 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
             rays += (unsigned)(remaining - 1);  // one camera-ray query per sample; the first is already counted
             for (int k = 0; k < sample_count; ++k) {
                 if (scratch_slot >= 0) {
-                    scratch[(size_t)k * PT_TILE_THREADS] = make_float4(sr, sg, sb, 0.f);
+                    park(&scratch[(size_t)k * PT_TILE_THREADS], sr, sg, sb, 1.0f, rd0.y);
                 } else if (p.accum_mode == 0) {
                     if (mr == sr && mg == sg && mb == sb) break;
                     const float a = ieee_rcp((float)sample);
@@ -931,7 +938,7 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
             float sr = ex * (omt + 0.5f * t), sg = ey * (omt + 0.7f * t), sb = ez * (omt + 1.0f * t);
             if (MATERIALS) { sr = sr + emitted.x; sg = sg + emitted.y; sb = sb + emitted.z; }
             if (scratch_slot >= 0) {
-                scratch[(size_t)(sample_count - remaining) * PT_TILE_THREADS] = make_float4(sr, sg, sb, 0.f);
+                park(&scratch[(size_t)(sample_count - remaining) * PT_TILE_THREADS], sr, sg, sb, energy.x, rd.y);
             } else if (p.accum_mode == 0) {
                 const float a = ieee_rcp(rng.samples);
                 mr = mr + a * (sr - mr);
@@ -1169,29 +1176,49 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_fold_samples_kernel(const 
     const size_t pix = (size_t)y * p.width + x;
     const float4 prev = reinterpret_cast<const float4*>(p.src)[pix];
     float mr = prev.x, mg = prev.y, mb = prev.z;
-    const float4* __restrict__ scratch = reinterpret_cast<const float4*>(p.sample_scratch) + (size_t)blockIdx.x * p.num_samples * PT_TILE_THREADS + threadIdx.x;
     int sample = p.first_sample;
-    auto fold = [&](const float4 s) {
+    auto fold = [&](float sr, float sg, float sb) {
         if (p.accum_mode == 0) {
             const float a = 1.0f / (float)sample;
-            mr = mr + a * (s.x - mr);
-            mg = mg + a * (s.y - mg);
-            mb = mb + a * (s.z - mb);
+            mr = mr + a * (sr - mr);
+            mg = mg + a * (sg - mg);
+            mb = mb + a * (sb - mb);
         } else {
-            mr += s.x; mg += s.y; mb += s.z;
+            mr += sr; mg += sg; mb += sb;
         }
         sample += p.sample_stride;
     };
     // the folds form one dependent chain; the loads do not, so they are issued eight at a time ahead of it
-    int k = 0;
-    for (; k + 8 <= p.num_samples; k += 8) {
-        float4 s[8];
+    const size_t first = (size_t)blockIdx.x * p.num_samples * PT_TILE_THREADS + threadIdx.x;
+    if (p.shading_mode == 1) {
+        const float4* __restrict__ scratch = reinterpret_cast<const float4*>(p.sample_scratch) + first;
+        int k = 0;
+        for (; k + 8 <= p.num_samples; k += 8) {
+            float4 s[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s[j] = scratch[(size_t)(k + j) * PT_TILE_THREADS];
+            for (int j = 0; j < 8; ++j) s[j] = scratch[(size_t)(k + j) * PT_TILE_THREADS];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) fold(s[j]);
+            for (int j = 0; j < 8; ++j) fold(s[j].x, s[j].y, s[j].z);
+        }
+        for (; k < p.num_samples; ++k) { const float4 v = scratch[(size_t)k * PT_TILE_THREADS]; fold(v.x, v.y, v.z); }
+    } else {
+        // (throughput, final direction's y) -> fs:408-410 as in the render kernel
+        auto fold_sky = [&](float2 v) {
+            const float t = 0.5f * (v.y + 1.0f);
+            const float omt = 1.0f - t;
+            fold(v.x * (omt + 0.5f * t), v.x * (omt + 0.7f * t), v.x * (omt + 1.0f * t));
+        };
+        const float2* __restrict__ scratch = reinterpret_cast<const float2*>(p.sample_scratch) + first;
+        int k = 0;
+        for (; k + 8 <= p.num_samples; k += 8) {
+            float2 s[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] = scratch[(size_t)(k + j) * PT_TILE_THREADS];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fold_sky(s[j]);
+        }
+        for (; k < p.num_samples; ++k) fold_sky(scratch[(size_t)k * PT_TILE_THREADS]);
     }
-    for (; k < p.num_samples; ++k) fold(scratch[(size_t)k * PT_TILE_THREADS]);
     const float alpha = p.accum_mode == 0 ? 1.0f : prev.w + (float)p.num_samples;
     reinterpret_cast<float4*>(p.dst)[pix] = make_float4(mr, mg, mb, alpha);
 }
