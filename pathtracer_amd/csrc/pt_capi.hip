@@ -903,6 +903,7 @@ PtStatus dispatch_range(PtContext* ctx, int32_t first_sample, int32_t num_sample
                 // split tiles park their samples in scratch memory: 8 (materials mode 16) bytes per pixel and sample
                 const size_t need = (size_t)c[1] * slot_bytes;
                 if (need > ctx->sample_scratch_bytes) {
+                    ctx->list_valid = false;  // (stays so if the allocation fails: no list may outlive its scratch)
                     if (ctx->d_sample_scratch) (void)hipFree(ctx->d_sample_scratch);
                     ctx->d_sample_scratch = nullptr;
                     ctx->sample_scratch_bytes = 0;
