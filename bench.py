@@ -274,11 +274,11 @@ def main():
                                        "latency-bound pointer chasing served by L2/Infinity Cache, far below the HBM roof"}
         if large:
             out["large_scene"] = large
-        # HBM bytes per launch from rocprofv3 PMC passes of this same workload (profiles/r01_pmc_cornell_grid_v2.json:
-        # FETCH_SIZE 21304.25 KB doubled as the gfx950 correction prescribes, plus WRITE_SIZE 359099.9 KB, of which 33 MB are
+        # HBM bytes per launch from rocprofv3 PMC passes of this same workload (profiles/r01_pmc_cornell_grid_v5.json:
+        # FETCH_SIZE 20765 KB doubled as the gfx950 correction prescribes, plus WRITE_SIZE 156372.75 KB, of which 33 MB are
         # the image and the rest the parked samples of split tiles); counters cannot be read from inside this run
         if args.workload == "cornell" and (W, H, spp) == (1920, 1080, 256):
-            out["roofline"]["traffic"] = 2 * 21304.25 * 1024 + 359099.875 * 1024
+            out["roofline"]["traffic"] = 2 * 20765.0 * 1024 + 156372.75 * 1024
             out["roofline"]["valu_issue_busy"] = 0.74
         # the reference shader itself on Mesa llvmpipe, same scene, camera and passes: recorded in the build container (the
         # shader text does not travel to the GPU box), see oracle/time_c1.py --c2
