@@ -84,6 +84,14 @@ def main(argv=None):
             window = (x0, y0, int(rng.integers(1, W - x0 + 1)), int(rng.integers(1, H - y0 + 1)))
         else:
             window = None
+        # a quarter of the mesh cases use the diffuse/emissive mode: random table of up to 10 rows (some emitters), one id per triangle
+        materials_mode = bool(kind == 1 and rng.random() < 0.25)
+        rows = int(rng.integers(1, 11))
+        table = rng.uniform(0.05, 0.95, (rows, 4)).astype(np.float32)
+        table[:, 3] = np.where(rng.random(rows) < 0.3, rng.uniform(0.5, 20.0, rows), 0.0).astype(np.float32)
+        mat_ids = rng.integers(0, rows, len(idx)).astype(np.int32)
+        if materials_mode and accel in (3, 4):
+            accel = 0
         first0 = int(rng.integers(1, 50))
         stride = 1 if mean else int(rng.integers(1, 9))
         counts = [int(rng.choice([1, 2, 7, 33, 96])) for _ in range(int(rng.integers(1, 4)))]
@@ -92,10 +100,12 @@ def main(argv=None):
         prog = t.program_create(kind)
         t.use_program(prog)
         t.upload_spheres(sph)
-        t.upload_materials(mat)
+        t.upload_materials(table if materials_mode else mat)
         t.upload_mesh(verts, idx)
+        if materials_mode:
+            t.upload_material_ids(mat_ids)
         t.set_normal_mode(normal_mode)
-        t.set_shading_mode(0)
+        t.set_shading_mode(1 if materials_mode else 0)
         t.set_accum_mode(capi.ACCUM_MEAN if mean else capi.ACCUM_SUM)
         t.set_primary_reuse(reuse)
         t.target_create(W, H)
@@ -105,8 +115,8 @@ def main(argv=None):
         t.set_accel_mode(accel)
         if window:
             t.set_window(*window)
-        scene = po.Scene(verts, idx, sph, mat)
-        u = po.uniforms(cam, W, H, ntri, depth, kind, normal_mode)
+        scene = po.Scene(verts, idx, sph, table if materials_mode else mat, mat_ids if materials_mode else None)
+        u = po.uniforms(cam, W, H, ntri, depth, kind, normal_mode, 1 if materials_mode else 0)
         ids, ts = t.readback_primary()
         oids, ots, _ = po.primary(scene, u, window=window, threads=args.threads)
         t.reset_stats()
@@ -141,7 +151,7 @@ def main(argv=None):
         bad_cases += 0 if ok else 1
         total_rays += int(st["rays"])
         print(json.dumps({"case": case, "scene": str(pick) if kind else "spheres", "triangles": ntri, "size": [W, H], "window": window,
-                          "depth": depth, "accel": accel, "reuse": reuse, "mean": mean, "stride": stride, "dispatches": plan,
+                          "depth": depth, "shading": "materials" if materials_mode else "reference", "accel": accel, "reuse": reuse, "mean": mean, "stride": stride, "dispatches": plan,
                           "differing_words": diff, "nan_words": int(both_nan.sum()), "differing_ids": id_diff, "differing_t": t_diff, "ray_count_difference": ray_diff}),
               flush=True)
         if args.only >= 0:
@@ -152,6 +162,7 @@ def main(argv=None):
         if window:
             t.set_window(0, 0, 0, 0)
         t.set_accel_mode(0)
+        t.set_shading_mode(0)
         t.program_destroy(prog)
     t.close()
     print(json.dumps({"cases": args.cases, "seed": args.seed, "cases_with_differences": bad_cases, "rays_compared": total_rays}))
