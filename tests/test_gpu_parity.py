@@ -552,3 +552,32 @@ def test_long_first_dispatch_probes_then_schedules():
         assert n_bit_mismatch(whole, t.readback()) == 0
     finally:
         t.close()
+
+
+def test_sparse_view_with_eager_split_equals_frame_by_frame():
+    """monkeyhead2 at 1920x1080: the work sits in a few hundred tiles, so after the first list the scheduler splits eagerly
+    (many pieces per tile, parked samples folded afterwards). Three 64-sample dispatches -- probe + first list, rebuilt list
+    with the eager factor, reused list -- must each give the image of 64 single-sample dispatches, and the reference's ray
+    count."""
+    from pathtracer_amd import Tracer
+    from pathtracer_amd.scenes import SceneData
+    scene = SceneData("monkeyhead2")
+    t = Tracer(0)
+    try:
+        scene.upload(t)
+        t.set_accum_mode(0)
+        t.target_create(scene.width, scene.height)
+        for s in range(1, 65):
+            t.dispatch(s, 1, 1)
+        t.finish()
+        frames = t.readback()
+        rays = t.stats()["rays"]
+        for _ in range(3):
+            t.target_clear()
+            t.reset_stats()
+            t.dispatch(1, 64, 1)
+            t.finish()
+            assert n_bit_mismatch(t.readback(), frames) == 0
+            assert t.stats()["rays"] == rays
+    finally:
+        t.close()
