@@ -882,12 +882,15 @@ PtStatus dispatch_range(PtContext* ctx, int32_t first_sample, int32_t num_sample
                     const int max_split = splitting ? (int)(factor * (float)ctx->wave_slots) : 0;
                     PT_HIP_TRY(pt_launch_schedule_items(ctx->d_tile_cost, ctx->d_items, ctx->d_sched_counts, ctx->d_split_tiles, tiles,
                                                         num_samples, max_split, ctx->stream));
+                    if (!splitting) {  // single-sample dispatches (frame loops): whole tiles in cost order, nothing to read back
+                        c[0] = (uint32_t)tiles; c[1] = 0;
+                        break;
+                    }
                     PT_HIP_TRY(hipMemcpyAsync(c, ctx->d_sched_counts, sizeof c, hipMemcpyDeviceToHost, ctx->stream));
                     PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
                     if (getenv("PT_DEBUG_SCHED"))
                         fprintf(stderr, "[pt sched] %d tiles, %d samples, costs from %lld samples, factor %g: %u items, %u split tiles\n", tiles,
                                 num_samples, (long long)ctx->cost_samples, (double)factor, c[0], c[1]);
-                    if (!splitting) break;
                     if (ctx->split_factor < 0.f && factor == 1.0f && c[1] >= (uint32_t)(ctx->wave_slots / 5)) {
                         factor = (float)PT_MAX_SPLIT_FACTOR;  // work concentrated in few tiles
                         ctx->concentrated = true;
