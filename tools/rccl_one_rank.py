@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""The multi-GPU step of bench.py with the real RCCL backend on ONE GPU (world size 1): process group over "nccl", render
+into a torch tensor on a side stream, all-reduce that tensor in place, barrier. Checks that the reduced image equals the
+rendered one and that nothing hangs -- the part of the N-GPU path a one-GPU box can exercise with the real backend."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    from pathtracer_amd import Tracer, capi
+    from pathtracer_amd.scenes import SceneData
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    torch.cuda.set_device(0)
+    device = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+    scene = SceneData("cornell", 640, 360)
+    t = Tracer(0)
+    stream = torch.cuda.Stream(device=device)
+    t.set_stream(stream.cuda_stream)
+    scene.upload(t)
+    image = torch.zeros((scene.height, scene.width, 4), dtype=torch.float32, device=device)
+    t.target_bind_external(image.data_ptr(), image.data_ptr(), scene.width, scene.height)
+    t.set_accum_mode(capi.ACCUM_SUM)
+    t0 = time.perf_counter()
+    for step in range(5):
+        with torch.cuda.stream(stream):
+            image.zero_()
+            t.dispatch(1, 32, 1)
+            before = image.clone()
+            dist.all_reduce(image, op=dist.ReduceOp.SUM)   # what pathtracer_amd.dist does for world sizes above 1
+            image.mul_(1.0 / 32.0)
+        stream.synchronize()
+        torch.cuda.synchronize(device)
+        dist.barrier()
+        assert torch.equal(image, before * (1.0 / 32.0)), "all-reduce over one rank changed the image"
+    print(f"ok: 5 steps of render + RCCL all-reduce + barrier on one rank in {time.perf_counter() - t0:.3f} s")
+    t.close()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
