@@ -58,6 +58,8 @@ def main(argv=None):
         else:
             verts, idx, normal_mode = assets[pick].vertices, assets[pick].indices, int(assets[pick].normal_mode)
         W, H = int(rng.integers(1, 150)), int(rng.integers(1, 110))
+        if rng.random() < 0.04:   # now and then an image of thousands of tiles (the scheduler's other regime)
+            W, H = int(rng.integers(300, 800)), int(rng.integers(200, 500))
         lo, hi = verts[:, :3].min(0), verts[:, :3].max(0)
         mid, ext = 0.5 * (lo + hi), float(np.linalg.norm(hi - lo)) + 1e-3
         where = rng.integers(0, 3)
