@@ -280,6 +280,8 @@ def main():
         if args.workload == "cornell" and (W, H, spp) == (1920, 1080, 256):
             out["roofline"]["traffic"] = 2 * 20765.0 * 1024 + 156372.75 * 1024
             out["roofline"]["valu_issue_busy"] = 0.74
+            out["roofline"]["hbm_GB_per_s"] = out["roofline"]["traffic"] / (kernel_ms * 1e-3) * 1e-9   # against the 8000 GB/s peak: the path is not HBM-bound
+            out["roofline"]["hbm_frac"] = out["roofline"]["hbm_GB_per_s"] / 8000.0
         # the reference shader itself on Mesa llvmpipe, same scene, camera and passes: recorded in the build container (the
         # shader text does not travel to the GPU box), see oracle/time_c1.py --c2
         gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "c2_cornell_1080p.json")
