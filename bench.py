@@ -72,6 +72,10 @@ def main():
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--spp", type=int, default=256, help="samples per pixel per step and per GPU")
+    ap.add_argument("--partition", default="sample", choices=["sample", "tile"],
+                    help="with --gpus N > 1: 'sample' = every GPU renders its own --spp samples of the whole frame (weak scaling, "
+                         "all-reduce of sums); 'tile' = the GPUs share the rows of ONE frame of --spp samples in interleaved blocks "
+                         "(strong scaling, bit-identical to one GPU, merged by an exact sum)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-second-scene", action="store_true", help="skip the short 1M-triangle run reported under 'large_scene'")
     ap.add_argument("--lean", action="store_true", help="warm-up and timed steps only (no CPU baseline, no 1M-triangle run, no "
@@ -116,19 +120,26 @@ def main():
     # the accumulation image lives in a torch tensor so that RCCL can reduce it in place
     image = torch.zeros((H, W, 4), dtype=torch.float32, device=device)
     tracer.target_bind_external(image.data_ptr(), image.data_ptr(), W, H)
-    sample_split = world > 1
+    sample_split = world > 1 and args.partition == "sample"
+    tile_split = world > 1 and args.partition == "tile"
     tracer.set_accum_mode(capi.ACCUM_SUM if sample_split else capi.ACCUM_MEAN)
-    first, stride, count = ptdist.sample_indices(rank, world, spp * world)
+    if tile_split:
+        first, stride, count = 1, 1, spp
+        tracer.set_row_interleave(16, rank, world)
+    else:
+        first, stride, count = ptdist.sample_indices(rank, world, spp * world)
     tracer.enable_timing(True)
 
     def step():
         with torch.cuda.stream(stream):
             image.zero_()
-            if not sample_split:
+            if not sample_split and not tile_split:
                 image[..., 3] = 1.0
             tracer.dispatch(first, count, stride)
             if sample_split:
                 ptdist.merge_sample_split(image, spp * world)
+            elif tile_split:
+                ptdist.merge_tile_split(image, H)   # rows of other ranks are zero here: the sum moves bytes, nothing else
 
     def fence():
         stream.synchronize()
@@ -223,14 +234,15 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if tile_split else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": {"cornell": "synthetic camera on the reference cornell_box.obj", "instanced": "synthetic: 254 jittered instances of the reference suzanne.obj (fixed LCG seed)"}.get(args.workload, "reference OBJ asset, reference camera"),
-            "config": {"workload": f"{scene.name} {W}x{H}, {spp} spp per GPU per step, depth 10, " +
+            "config": {"workload": f"{scene.name} {W}x{H}, {spp} spp per {'frame (one frame per step, rows shared by the GPUs)' if tile_split else 'GPU per step'}, depth 10, " +
                                    (f"{scene.num_triangles} triangles, closest hit through the direction grid (PT_ACCEL_AUTO)"
                                     if scene.program == 1 else "the reference's 10 spheres (IntersectWorld)"),
-                       "parallelism": "single GPU" if world == 1 else f"sample split over {world} GPUs + RCCL all-reduce"},
+                       "parallelism": "single GPU" if world == 1 else (f"image rows in interleaved blocks of 16 over {world} GPUs, merged by an exact sum (RCCL all-reduce)"
+                                                                           if tile_split else f"sample split over {world} GPUs + RCCL all-reduce")},
             "rays_definition": "closest-hit queries as the reference counts them: one per bounce-loop iteration of every sample "
                                "(PathTracer.cpp:947). The shader has no pixel jitter, so the first query of every sample of a pixel "
                                "is the same; it is evaluated once per dispatch and pixel and reused (bit-identical image). "

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 3
+#define PT_ABI_VERSION 4
 
 typedef enum PtStatus {
     PT_OK = 0,
@@ -192,6 +192,13 @@ PtStatus pt_target_clear(PtContext* ctx);
 /* Restricts rendering to the pixel window [x0,x0+w) x [y0,y0+h) (glScissor semantics); pixels outside keep their
  * value. Used for the image-tile partition across GPUs. w = h = 0 restores the full frame. */
 PtStatus pt_set_window(PtContext* ctx, int32_t x0, int32_t y0, int32_t w, int32_t h);
+/* No counterpart in the reference (one GPU, whole frame). Image-tile partition across `count` renderers in ONE dispatch
+ * each: the image rows are cut into blocks of `block_rows`, dealt round-robin, and this context renders only the blocks
+ * whose number is `index` modulo `count` (inside the current window); all other pixels keep their value. Interleaving
+ * shares out the expensive regions of an image. Every renderer runs all samples of its pixels with the reference
+ * recurrence, so its pixels are bit-identical to a single-renderer image; images that are zero outside the owned rows are
+ * merged exactly by a sum. count <= 1 switches it off. */
+PtStatus pt_set_row_interleave(PtContext* ctx, int32_t block_rows, int32_t index, int32_t count);
 PtStatus pt_set_accum_mode(PtContext* ctx, PtAccumMode mode);
 
 /* ---- per-frame: replaces PathTracer.cpp:1370-1403 ------------------------------------------------------ */

@@ -63,6 +63,7 @@ SIGNATURES = {
     "pt_target_bind_external": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     "pt_target_clear": (C.c_int, [C.c_void_p]),
     "pt_set_window": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "pt_set_row_interleave": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "pt_set_accum_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "pt_set_uniforms": (C.c_int, [C.c_void_p, C.POINTER(PtUniforms)]),
     "pt_dispatch": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
@@ -195,6 +196,10 @@ class Tracer:
 
     def set_window(self, x0=0, y0=0, w=0, h=0):
         check(self._lib.pt_set_window(self._ctx, x0, y0, w, h), self._lib)
+
+    def set_row_interleave(self, block_rows=16, index=0, count=1):
+        """Render only the row blocks `index` modulo `count` (image-tile partition in one dispatch); count <= 1: all rows."""
+        check(self._lib.pt_set_row_interleave(self._ctx, block_rows, index, count), self._lib)
 
     def set_accum_mode(self, mode):
         check(self._lib.pt_set_accum_mode(self._ctx, mode), self._lib)

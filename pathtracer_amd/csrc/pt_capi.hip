@@ -121,6 +121,7 @@ struct PtContext {
     int list_entry_bytes = 0;             // bytes per parked sample the scratch was sized for
     int list_items = 0, list_split = 0;   // what the scheduler produced: items and split tiles (launch sizes)
     bool concentrated = false;            // the work of this view sits in few tiles: lists are built with the eager split factor
+    int32_t row_block = 0, row_index = 0, row_count = 1;  // pt_set_row_interleave
     bool costs_stale = false;             // the tile costs were gathered for another mesh or camera position
     // the work list built last and what it was built for; reused while nothing it depends on changes
     bool list_valid = false;
@@ -353,6 +354,7 @@ PtStatus fill_params(PtContext* ctx, PtKernelParams* p, const Program** prog_out
     p->width = ctx->width;
     p->height = ctx->height;
     p->win_x0 = ctx->win[0]; p->win_y0 = ctx->win[1]; p->win_w = ctx->win[2]; p->win_h = ctx->win[3];
+    p->row_block = ctx->row_block > 0 ? ctx->row_block : 1; p->row_index = ctx->row_index; p->row_count = ctx->row_count;
     p->depth = u.depth;
     p->accum_mode = (int32_t)ctx->accum_mode;
     p->normal_mode = (int32_t)ctx->normal_mode;
@@ -811,6 +813,19 @@ PtStatus pt_set_window(PtContext* ctx, int32_t x0, int32_t y0, int32_t w, int32_
     return PT_OK;
 }
 
+PtStatus pt_set_row_interleave(PtContext* ctx, int32_t block_rows, int32_t index, int32_t count) {
+    PT_REQUIRE(ctx != nullptr, PT_ERR_INVALID_ARGUMENT, "null context");
+    if (count <= 1) {
+        ctx->row_block = 0; ctx->row_index = 0; ctx->row_count = 1;
+    } else {
+        PT_REQUIRE(block_rows >= 1 && index >= 0 && index < count, PT_ERR_INVALID_ARGUMENT,
+                   "row interleave: block_rows %d must be >= 1 and index %d in [0, %d)", block_rows, index, count);
+        ctx->row_block = block_rows; ctx->row_index = index; ctx->row_count = count;
+    }
+    ctx->sched_have_cost = false;  // another set of pixels: the tile costs no longer apply
+    return PT_OK;
+}
+
 PtStatus pt_set_accum_mode(PtContext* ctx, PtAccumMode mode) {
     PT_REQUIRE(ctx != nullptr, PT_ERR_INVALID_ARGUMENT, "null context");
     PT_REQUIRE(mode == PT_ACCUM_MEAN || mode == PT_ACCUM_SUM, PT_ERR_INVALID_ARGUMENT, "unknown accumulation mode %d", (int)mode);
@@ -841,7 +856,7 @@ PtStatus dispatch_range(PtContext* ctx, int32_t first_sample, int32_t num_sample
     p.dst = ctx->d_image[ctx->current];
     p.src = ctx->d_image[ctx->current ^ 1];
     // A pass only rewrites the window; with two distinct images the pixels outside it must follow the swap.
-    const bool partial = ctx->win[2] != ctx->width || ctx->win[3] != ctx->height;
+    const bool partial = ctx->win[2] != ctx->width || ctx->win[3] != ctx->height || ctx->row_count > 1;
     if (partial && p.dst != p.src) {
         PT_HIP_TRY(hipMemcpyAsync(p.dst, p.src, (size_t)ctx->width * ctx->height * 16, hipMemcpyDeviceToDevice, ctx->stream));
     }
@@ -945,7 +960,12 @@ PtStatus dispatch_range(PtContext* ctx, int32_t first_sample, int32_t num_sample
     }
     PT_HIP_TRY(pt_launch_render(p, (int)prog->kind, ctx->stream));
     ctx->current ^= 1;  // PathTracer.cpp:1493
-    ctx->samples += (uint64_t)ctx->win[2] * ctx->win[3] * (uint64_t)num_samples;
+    uint64_t rows = (uint64_t)ctx->win[3];
+    if (ctx->row_count > 1) {  // rows of the window that belong to this renderer
+        rows = 0;
+        for (int y = ctx->win[1]; y < ctx->win[1] + ctx->win[3]; ++y) rows += (y / ctx->row_block) % ctx->row_count == ctx->row_index;
+    }
+    ctx->samples += (uint64_t)ctx->win[2] * rows * (uint64_t)num_samples;
     return PT_OK;
 }
 }  // namespace

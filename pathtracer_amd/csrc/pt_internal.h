@@ -132,6 +132,7 @@ struct PtKernelParams {
     float ro[3], llc[3], hor[3], ver[3];
     int32_t width, height;              // full frame: textureSize(u_Texture, 0)
     int32_t win_x0, win_y0, win_w, win_h;
+    int32_t row_block, row_index, row_count;  // row_count > 1: only rows whose block (y / row_block) is row_index modulo row_count are rendered
     int32_t num_triangles, depth;
     int32_t first_sample, num_samples, sample_stride;
     int32_t accum_mode;                 // PtAccumMode

@@ -736,7 +736,9 @@ __device__ __forceinline__ bool pixel_of_lane(const PtKernelParams& p, int tile,
     const int ly = ty * PT_TILE_DIM + (wave >> 1) * 8 + (lane >> 3);
     x = p.win_x0 + lx;
     y = p.win_y0 + ly;
-    return lx < p.win_w && ly < p.win_h;
+    bool mine = lx < p.win_w && ly < p.win_h;
+    if (p.row_count > 1) mine = mine && (y / p.row_block) % p.row_count == p.row_index;  // image-tile partition by interleaved row blocks
+    return mine;
 }
 
 // fs:381-383

@@ -581,3 +581,39 @@ def test_sparse_view_with_eager_split_equals_frame_by_frame():
             assert t.stats()["rays"] == rays
     finally:
         t.close()
+
+
+@pytest.mark.parametrize("block,count", [(16, 3), (5, 2), (8, 8)])
+def test_row_interleave_partition_is_exact(tracer, block, count):
+    """Image-tile partition in one dispatch per renderer: each renders the row blocks `index` modulo `count`; its rows are bit
+    for bit those of the whole-frame render, everything else stays at the clear value, the parts sum to the whole frame, and
+    the sample counts add up. Twice per part, so that the second dispatch runs from a work list."""
+    from pathtracer_amd import dist as ptdist
+    fx = load_case("monkey_mesh_128")
+    t = tracer
+    prog = setup_case(t, fx)
+    H = 128
+    t.dispatch(1, 6, 1)
+    t.finish()
+    full = t.readback()
+    total = np.zeros_like(full)
+    samples = 0
+    for index in range(count):
+        t.set_row_interleave(block, index, count)
+        for _ in range(2):
+            t.target_clear()
+            t.reset_stats()
+            t.dispatch(1, 6, 1)
+            t.finish()
+        part = t.readback()
+        own = np.zeros(H, bool)
+        for y0, h in ptdist.row_blocks(index, count, H, block):
+            own[y0:y0 + h] = True
+        assert n_bit_mismatch(part[own], full[own]) == 0
+        assert np.all(part[~own][..., :3] == 0)
+        total[own] = part[own]
+        samples += t.stats()["samples"]
+    t.set_row_interleave(block, 0, 1)
+    assert n_bit_mismatch(total, full) == 0
+    assert samples == 128 * 128 * 6
+    t.program_destroy(prog)
