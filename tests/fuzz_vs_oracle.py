@@ -94,6 +94,11 @@ def main(argv=None):
         mat_ids = rng.integers(0, rows, len(idx)).astype(np.int32)
         if materials_mode and accel in (3, 4):
             accel = 0
+        # now and then only the row blocks of one of several renderers (image-tile partition)
+        interleave = None
+        if rng.random() < 0.15:
+            cnt = int(rng.integers(2, 6))
+            interleave = (int(rng.choice([1, 3, 8, 16])), int(rng.integers(0, cnt)), cnt)
         first0 = int(rng.integers(1, 50))
         stride = 1 if mean else int(rng.integers(1, 9))
         counts = [int(rng.choice([1, 2, 7, 33, 96])) for _ in range(int(rng.integers(1, 4)))]
@@ -117,6 +122,22 @@ def main(argv=None):
         t.set_accel_mode(accel)
         if window:
             t.set_window(*window)
+        if interleave:
+            t.set_row_interleave(*interleave)
+        wx0, wy0, ww, wh = window if window else (0, 0, W, H)
+        if interleave:   # the oracle renders the owned row blocks one by one, as windows
+            blk, idx_r, cnt = interleave
+            owned_rows = [y for y in range(wy0, wy0 + wh) if (y // blk) % cnt == idx_r]
+            runs, start = [], None
+            for y in range(wy0, wy0 + wh + 1):
+                mine = y < wy0 + wh and (y // blk) % cnt == idx_r
+                if mine and start is None:
+                    start = y
+                if not mine and start is not None:
+                    runs.append((wx0, start, ww, y - start)); start = None
+            oracle_windows = runs
+        else:
+            oracle_windows = [window]
         scene = po.Scene(verts, idx, sph, table if materials_mode else mat, mat_ids if materials_mode else None)
         u = po.uniforms(cam, W, H, ntri, depth, kind, normal_mode, 1 if materials_mode else 0)
         ids, ts = t.readback_primary()
@@ -128,11 +149,15 @@ def main(argv=None):
         for n in counts:
             plan.append((first, n))
             t.dispatch(first, n, stride)
-            if mean:
-                ref, r = po.render(scene, u, first, n, ref, window=window, threads=args.threads)
-            else:
-                ref, r = po.render_sum(scene, u, first, stride, n, ref, window=window, threads=args.threads)
-            oracle_rays += r
+            if mean and ref is None:
+                ref = np.zeros((H, W, 4), np.float32)
+                ref[..., 3] = 1.0
+            for ow in oracle_windows:
+                if mean:
+                    ref, r = po.render(scene, u, first, n, ref, window=ow, threads=args.threads)
+                else:
+                    ref, r = po.render_sum(scene, u, first, stride, n, ref, window=ow, threads=args.threads)
+                oracle_rays += r
             first += n * stride
         t.finish()
         img = t.readback()
@@ -146,14 +171,19 @@ def main(argv=None):
         a, b = img[sl][..., :3], ref[sl][..., :3]
         both_nan = np.isnan(a) & np.isnan(b)   # x86 and gfx950 generate default NaNs of opposite sign: a NaN is a NaN
         diff = int(((a.view(np.uint32) != b.view(np.uint32)) & ~both_nan).sum())
-        id_diff = int((ids[sl] != oids[sl]).sum())
-        t_diff = int((ts[sl].view(np.uint32) != ots[sl].view(np.uint32)).sum())
+        rowmask = np.ones(H, bool)
+        if interleave:   # the primary read-back fills in the renderer's own rows only
+            rowmask[:] = False
+            rowmask[owned_rows] = True
+        rm = rowmask[sl[0]]
+        id_diff = int((ids[sl][rm] != oids[sl][rm]).sum())
+        t_diff = int((ts[sl][rm].view(np.uint32) != ots[sl][rm].view(np.uint32)).sum())
         ray_diff = int(st["rays"]) - int(oracle_rays)
         ok = diff == 0 and id_diff == 0 and t_diff == 0 and ray_diff == 0
         bad_cases += 0 if ok else 1
         total_rays += int(st["rays"])
         print(json.dumps({"case": case, "scene": str(pick) if kind else "spheres", "triangles": ntri, "size": [W, H], "window": window,
-                          "depth": depth, "shading": "materials" if materials_mode else "reference", "accel": accel, "reuse": reuse, "mean": mean, "stride": stride, "dispatches": plan,
+                          "interleave": interleave, "depth": depth, "shading": "materials" if materials_mode else "reference", "accel": accel, "reuse": reuse, "mean": mean, "stride": stride, "dispatches": plan,
                           "differing_words": diff, "nan_words": int(both_nan.sum()), "differing_ids": id_diff, "differing_t": t_diff, "ray_count_difference": ray_diff}),
               flush=True)
         if args.only >= 0:
@@ -163,6 +193,8 @@ def main(argv=None):
                                   "primary_id": int(ids[sl][y, x])}))
         if window:
             t.set_window(0, 0, 0, 0)
+        if interleave:
+            t.set_row_interleave(16, 0, 1)
         t.set_accel_mode(0)
         t.set_shading_mode(0)
         t.program_destroy(prog)
