@@ -163,10 +163,12 @@ def test_million_triangle_scene_crops(tracer):
         assert (res["bvh"][0][y0:y0 + h, x0:x0 + w] >= 0).sum() > 100
 
 
-@pytest.mark.parametrize("workload,size,spp", [("instanced", (1920, 1080), 8), ("cornell", (960, 540), 32), ("suzanne", (640, 360), 48)])
+@pytest.mark.parametrize("workload,size,spp", [("instanced", (1920, 1080), 8), ("instanced", (3840, 2160), 16), ("cornell", (960, 540), 32),
+                                                ("suzanne", (640, 360), 48), ("suzanne", (1920, 1080), 64), ("monkeyhead2", (1920, 1080), 64)])
 def test_direction_grid_equals_hierarchy_on_full_frames(tracer, workload, size, spp):
     """Full frames, tens of millions of closest-hit queries in every direction a bounce can take: the direction grid
-    against the LBVH (itself pinned to the all-triangles loop above): ids, distances, radiance, ray counts."""
+    against the LBVH (itself pinned to the all-triangles loop above): ids, distances, radiance, ray counts. Includes the
+    1M-triangle scene and the two reference heads at the sizes the benchmark configurations name (4K; 1080p)."""
     from pathtracer_amd import capi
     from pathtracer_amd.scenes import SceneData
     sc = SceneData(workload, *size)
