@@ -617,3 +617,34 @@ def test_row_interleave_partition_is_exact(tracer, block, count):
     assert n_bit_mismatch(total, full) == 0
     assert samples == 128 * 128 * 6
     t.program_destroy(prog)
+
+
+def test_sample_split_over_eight_at_full_size():
+    """Configuration C3's partition at its own size: monkeyhead2 at 1920x1080, 1024 samples as eight residue classes of 128
+    (what eight GPUs render), summed and scaled, against the sequential running mean of the same 1024 samples: equal to
+    rounding (|difference| < 2e-6 on values in [0, 1]); ray counts of the parts add up to the whole."""
+    from pathtracer_amd import Tracer, capi
+    from pathtracer_amd.scenes import SceneData
+    scene = SceneData("monkeyhead2")
+    t = Tracer(0)
+    try:
+        scene.upload(t)
+        t.target_create(scene.width, scene.height)
+        t.set_accum_mode(capi.ACCUM_MEAN)
+        t.dispatch(1, 1024, 1)
+        t.finish()
+        mean = t.readback()[..., :3].copy()
+        rays = t.stats()["rays"]
+        t.reset_stats()
+        t.set_accum_mode(capi.ACCUM_SUM)
+        total = np.zeros_like(mean)
+        for r in range(8):
+            t.target_clear()
+            t.dispatch(1 + r, 128, 8)
+            t.finish()
+            total += t.readback()[..., :3]      # fp32 additions, like the all-reduce
+        assert t.stats()["rays"] == rays
+        assert total.dtype == np.float32
+        assert np.abs(total * np.float32(1.0 / 1024.0) - mean).max() < 2e-6
+    finally:
+        t.close()
