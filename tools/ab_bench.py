@@ -18,6 +18,8 @@ VARIANTS = {
     "base": [],
     "vfirst": ["-DPT_V_VFIRST"],
     "nosky": ["-DPT_V_NO_SKY"],
+    "maxilp": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+    "memclause": ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"],
 }
 
 
