@@ -209,3 +209,43 @@ def test_short_arithmetic_sequences_equal_ieee_for_every_input(tracer):
     """The kernels' 4-instruction reciprocal, unscaled square root and log2 quotient against the compiler's IEEE division and
     square root: all 2^32 float inputs (2^23 mantissas for the quotient), results compared bit for bit on the device."""
     assert tracer.selftest_arithmetic() == (0, 0, 0)
+
+
+@pytest.mark.parametrize("where", ["reference", "inside", "grazing", "far", "tiny"])
+def test_sphere_program_from_awkward_camera_positions(tracer, where):
+    """The sphere program with the camera at the reference position,
+    inside a sphere, almost on a surface, far away (spheres of a few pixels), and with the radii shrunk to a hundredth:
+    primary ids, distances, image and ray count against the oracle."""
+    fx = dict(load_case("world_128"))
+    sph = np.array(fx["spheres"], np.float32).reshape(10, 4).copy()
+    eye, target = (0.0, 0.0, 0.0), (0.0, 0.0, 1.0)
+    if where == "inside":
+        eye = tuple(sph[3, :3] + np.float32(0.3) * sph[3, 3])
+        target = tuple(sph[5, :3])
+    elif where == "grazing":
+        eye = tuple(sph[2, :3] + np.array([0, 1.0002, 0], np.float32) * sph[2, 3])
+        target = tuple(np.array(eye, np.float32) + np.array([1.0, -0.05, 0.2], np.float32))   # along the surface, slightly down
+    elif where == "far":
+        eye = (40.0, 25.0, -150.0)
+        target = tuple(sph[:, :3].mean(0))
+    elif where == "tiny":
+        sph[:, 3] *= np.float32(0.01)
+    fx["spheres"] = sph
+    W, H = 160, 120
+    cam = po.camera(60.0 if where != "far" else 8.0, W, H, eye, target, (0, 1, 0))
+    prog, scene, u = upload(tracer, fx, W, H, cam=cam, kind=0)
+    ids, ts = tracer.readback_primary()
+    tracer.reset_stats()
+    tracer.dispatch(1, 12, 1)
+    tracer.finish()
+    oids, ots, _ = po.primary(scene, u, threads=8)
+    ref, rays = po.render(scene, u, 1, 12, threads=8)
+    assert np.array_equal(ids, oids) and n_bit_mismatch(ts, ots) == 0
+    img = tracer.readback()
+    both_nan = np.isnan(img) & np.isnan(ref)
+    assert int(((img.view(np.uint32) != ref.view(np.uint32)) & ~both_nan).sum()) == 0
+    assert tracer.stats()["rays"] == rays
+    if where in ("reference", "inside", "far"):
+        assert (ids >= 0).sum() > 20
+    tracer.reset_stats()
+    tracer.program_destroy(prog)
