@@ -309,6 +309,7 @@ def main():
 
     tracer.close()
     if world > 1:
+        dist.barrier()   # rank 0 reports (CPU baseline, large scene) after the timed region: the ranks leave together
         dist.destroy_process_group()
 
 
