@@ -105,6 +105,7 @@ struct PtContext {
     uint32_t* d_tile_cost = nullptr;
     PtWorkItem* d_items = nullptr;        // tiles + max_split entries
     uint32_t* d_sched_counts = nullptr;   // 2
+    uint32_t* d_sched_tmp = nullptr;      // PT_SCHED_TMP_WORDS
     uint32_t* d_split_tiles = nullptr;    // max_split entries
     float* d_sample_scratch = nullptr;    // grows with the largest num_samples dispatched
     size_t sample_scratch_bytes = 0;
@@ -186,6 +187,8 @@ void free_target(PtContext* ctx) {
     if (ctx->d_tile_cost) (void)hipFree(ctx->d_tile_cost);
     if (ctx->d_items) (void)hipFree(ctx->d_items);
     if (ctx->d_sched_counts) (void)hipFree(ctx->d_sched_counts);
+    if (ctx->d_sched_tmp) (void)hipFree(ctx->d_sched_tmp);
+    ctx->d_sched_tmp = nullptr;
     if (ctx->d_split_tiles) (void)hipFree(ctx->d_split_tiles);
     if (ctx->d_sample_scratch) (void)hipFree(ctx->d_sample_scratch);
     ctx->d_items = nullptr;
@@ -754,6 +757,7 @@ static PtStatus target_common(PtContext* ctx, int32_t width, int32_t height) {
     PT_HIP_TRY(hipMalloc(&ctx->d_tile_cost, tiles * sizeof(uint32_t)));
     PT_HIP_TRY(hipMalloc(&ctx->d_items, (tiles + (size_t)PT_MAX_SPLIT_FACTOR * ctx->wave_slots) * sizeof(PtWorkItem)));
     PT_HIP_TRY(hipMalloc(&ctx->d_sched_counts, 2 * sizeof(uint32_t)));
+    PT_HIP_TRY(hipMalloc(&ctx->d_sched_tmp, PT_SCHED_TMP_WORDS * sizeof(uint32_t)));
     PT_HIP_TRY(hipMalloc(&ctx->d_split_tiles, (size_t)PT_MAX_SPLIT_FACTOR * ctx->wave_slots * sizeof(uint32_t)));
     ctx->sched_have_cost = false;
     return PT_OK;
@@ -895,7 +899,7 @@ PtStatus dispatch_range(PtContext* ctx, int32_t first_sample, int32_t num_sample
                 uint32_t c[2] = {0, 0};
                 for (;;) {
                     const int max_split = splitting ? (int)(factor * (float)ctx->wave_slots) : 0;
-                    PT_HIP_TRY(pt_launch_schedule_items(ctx->d_tile_cost, ctx->d_items, ctx->d_sched_counts, ctx->d_split_tiles, tiles,
+                    PT_HIP_TRY(pt_launch_schedule_items(ctx->d_tile_cost, ctx->d_items, ctx->d_sched_counts, ctx->d_split_tiles, ctx->d_sched_tmp, tiles,
                                                         num_samples, max_split, ctx->stream));
                     if (!splitting) {  // single-sample dispatches (frame loops): whole tiles in cost order, nothing to read back
                         c[0] = (uint32_t)tiles; c[1] = 0;

@@ -191,6 +191,7 @@ hipError_t pt_launch_present(const float* img, size_t num_pixels, uint32_t* out_
 // total / max_split_tiles are split into several items (at most num_samples), items ordered most expensive first.
 // Always: item count <= num_tiles + max_split_tiles and split tiles <= max_split_tiles. tile_cost is only read.
 // sched_counts <- {items, split tiles}.
-hipError_t pt_launch_schedule_items(const uint32_t* tile_cost, PtWorkItem* items, uint32_t* sched_counts, uint32_t* split_tiles, int num_tiles,
-                                    int num_samples, int max_split_tiles, hipStream_t stream);
+hipError_t pt_launch_schedule_items(const uint32_t* tile_cost, PtWorkItem* items, uint32_t* sched_counts, uint32_t* split_tiles, uint32_t* sched_tmp,
+                                    int num_tiles, int num_samples, int max_split_tiles, hipStream_t stream);
+#define PT_SCHED_TMP_WORDS (4 + 64 * 64)  // scratch of the scheduler's launches: total cost, per-workgroup bucket counts
 hipError_t pt_launch_primary(const PtKernelParams& p, int program_kind, hipStream_t stream);

@@ -1228,79 +1228,110 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_fold_samples_kernel(const 
 // Builds the work list of the next dispatch from the per-tile costs the previous one measured (loop trips per tile).
 // granule = total cost / max_split + 1: a tile above it is split into ceil(cost / granule) items of equal sample counts
 // (at most num_samples), so the extra items and the split tiles both stay below max_split. Items are placed most
-// expensive first by half-octave bucket of their cost (a counting sort done by one workgroup; positions inside a bucket
-// are handed out atomically, so the list is always a complete cover). The costs are left as they are (the caller may run the
-// scheduler again with another limit before clearing them).
-__global__ __launch_bounds__(1024) void pt_schedule_items_kernel(const uint32_t* __restrict__ cost, PtWorkItem* __restrict__ items,
-                                                                 uint32_t* __restrict__ counts, uint32_t* __restrict__ split_tiles, int n,
-                                                                 int num_samples, int max_split, int sort) {
-    __shared__ uint32_t hist[64], start[64];
-    __shared__ unsigned long long total;
-    __shared__ uint32_t num_split;
-    if (threadIdx.x < 64) hist[threadIdx.x] = 0;
-    if (threadIdx.x == 0) { total = 0; num_split = 0; }
-    __syncthreads();
-    // One workgroup walks all tiles several times; each thread fetches the costs of four of its tiles at once.
+// expensive first by half-octave bucket of their cost: a counting sort over PT_SCHED_BLOCKS workgroups in four small
+// launches (total, per-workgroup bucket counts, offsets, scatter); positions inside a workgroup's share of a bucket are
+// handed out atomically, so the list is always a complete cover whatever the order. The costs are only read (the caller
+// may run the scheduler again with another limit before clearing them).
+// tmp: [0..1] total cost (64 bit), [4 + 64 * block + bucket] that workgroup's count, then start, in the bucket.
+constexpr int PT_SCHED_BLOCKS = 64, PT_SCHED_THREADS = 256;
+
+__device__ __forceinline__ int sched_bucket(uint32_t c, int sort) {
+    if (!sort) return 0;
+    if (c < 2) return (int)c;
+    const int lg = 31 - __builtin_clz(c);
+    const int half = (int)((c >> (lg - 1)) & 1u);
+    const int b = 2 * lg + half;
+    return b > 63 ? 63 : b;
+}
+// pieces of a tile and samples per piece
+__device__ __forceinline__ int sched_split(uint32_t c, unsigned long long granule, int num_samples, int& per_piece) {
+    if ((unsigned long long)c <= granule) {  // the usual tile: one item (and none of the divisions below)
+        per_piece = num_samples;
+        return 1;
+    }
+    unsigned long long k = ((unsigned long long)c + granule - 1) / granule;
+    if (k < 1) k = 1;
+    if (k > (unsigned long long)num_samples) k = (unsigned long long)num_samples;
+    per_piece = (num_samples + (int)k - 1) / (int)k;
+    return (num_samples + per_piece - 1) / per_piece;
+}
+__device__ __forceinline__ unsigned long long sched_granule(const uint32_t* tmp, int max_split) {
+    const unsigned long long total = *reinterpret_cast<const unsigned long long*>(tmp);
+    return max_split > 0 ? total / (unsigned long long)max_split + 1ull : ~0ull;
+}
+// the tiles of workgroup b: one contiguous share
+__device__ __forceinline__ void sched_share(int n, int& begin, int& end) {
+    const int per = (n + PT_SCHED_BLOCKS - 1) / PT_SCHED_BLOCKS;
+    begin = (int)blockIdx.x * per;
+    end = begin + per < n ? begin + per : n;
+}
+
+__global__ __launch_bounds__(PT_SCHED_THREADS) void pt_sched_total_kernel(const uint32_t* __restrict__ cost, int n, uint32_t* __restrict__ tmp) {
     unsigned long long mine = 0;
-#pragma unroll 4
-    for (int i = threadIdx.x; i < n; i += blockDim.x) mine += cost[i];
-    atomicAdd(&total, mine);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) mine += cost[i];
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(reinterpret_cast<unsigned long long*>(tmp), mine);
+}
+
+__global__ __launch_bounds__(PT_SCHED_THREADS) void pt_sched_count_kernel(const uint32_t* __restrict__ cost, int n, int num_samples, int max_split,
+                                                                          int sort, uint32_t* __restrict__ tmp) {
+    __shared__ uint32_t hist[64];
+    if (threadIdx.x < 64) hist[threadIdx.x] = 0;
     __syncthreads();
-    const unsigned long long granule = max_split > 0 ? total / (unsigned long long)max_split + 1ull : ~0ull;
-    auto bucket = [sort](uint32_t c) -> int {
-        if (!sort) return 0;
-        if (c < 2) return (int)c;
-        const int lg = 31 - __builtin_clz(c);
-        const int half = (int)((c >> (lg - 1)) & 1u);
-        const int b = 2 * lg + half;
-        return b > 63 ? 63 : b;
-    };
-    // pieces of a tile and samples per piece
-    auto split = [granule, num_samples](uint32_t c, int& per_piece) -> int {
-        if ((unsigned long long)c <= granule) {  // the usual tile: one item (and none of the divisions below, which are long
-            per_piece = num_samples;             // instruction sequences that one workgroup would run for every tile)
-            return 1;
-        }
-        unsigned long long k = ((unsigned long long)c + granule - 1) / granule;
-        if (k < 1) k = 1;
-        if (k > (unsigned long long)num_samples) k = (unsigned long long)num_samples;
-        per_piece = (num_samples + (int)k - 1) / (int)k;
-        return (num_samples + per_piece - 1) / per_piece;
-    };
-    const int step4 = 4 * (int)blockDim.x;
-    for (int i0 = threadIdx.x; i0 < n; i0 += step4) {
-        uint32_t c[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { const int i = i0 + j * (int)blockDim.x; c[j] = i < n ? cost[i] : 0u; }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (i0 + j * (int)blockDim.x >= n) break;
-            int per_piece;
-            const int k = split(c[j], per_piece);
-            atomicAdd(&hist[bucket(c[j] / (uint32_t)k)], (uint32_t)k);
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t acc = 0;
-        for (int b = 63; b >= 0; --b) { start[b] = acc; acc += hist[b]; }
-        counts[0] = acc;
-    }
-    __syncthreads();
-    for (int i0 = threadIdx.x; i0 < n; i0 += step4) {
-      uint32_t c[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { const int i = i0 + j * (int)blockDim.x; c[j] = i < n ? cost[i] : 0u; }
-#pragma unroll
-      for (int j4 = 0; j4 < 4; ++j4) {
-        const int i = i0 + j4 * (int)blockDim.x;
-        if (i >= n) break;
+    const unsigned long long granule = sched_granule(tmp, max_split);
+    int begin, end;
+    sched_share(n, begin, end);
+    for (int i = begin + (int)threadIdx.x; i < end; i += blockDim.x) {
         int per_piece;
-        const int k = split(c[j4], per_piece);
-        const uint32_t first = atomicAdd(&start[bucket(c[j4] / (uint32_t)k)], (uint32_t)k);
+        const uint32_t c = cost[i];
+        const int k = sched_split(c, granule, num_samples, per_piece);
+        atomicAdd(&hist[sched_bucket(c / (uint32_t)k, sort)], (uint32_t)k);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) tmp[4 + 64 * blockIdx.x + threadIdx.x] = hist[threadIdx.x];
+}
+
+// One workgroup of 64 threads, thread = bucket: counts -> start of every workgroup's share of the bucket in the list
+// (most expensive bucket first); counts[0] <- number of items, counts[1] <- 0 (the scatter counts the split tiles there).
+__global__ __launch_bounds__(64) void pt_sched_offsets_kernel(uint32_t* __restrict__ tmp, uint32_t* __restrict__ counts) {
+    __shared__ uint32_t bucket_total[64], bucket_base[64];
+    const int b = threadIdx.x;
+    uint32_t running = 0;
+    for (int blk = 0; blk < PT_SCHED_BLOCKS; ++blk) {
+        const uint32_t v = tmp[4 + 64 * blk + b];
+        tmp[4 + 64 * blk + b] = running;
+        running += v;
+    }
+    bucket_total[b] = running;
+    __syncthreads();
+    if (b == 0) {
+        uint32_t acc = 0;
+        for (int k = 63; k >= 0; --k) { bucket_base[k] = acc; acc += bucket_total[k]; }
+        counts[0] = acc;
+        counts[1] = 0;
+    }
+    __syncthreads();
+    const uint32_t base = bucket_base[b];
+    for (int blk = 0; blk < PT_SCHED_BLOCKS; ++blk) tmp[4 + 64 * blk + b] += base;
+}
+
+__global__ __launch_bounds__(PT_SCHED_THREADS) void pt_sched_scatter_kernel(const uint32_t* __restrict__ cost, int n, int num_samples, int max_split,
+                                                                            int sort, const uint32_t* __restrict__ tmp, PtWorkItem* __restrict__ items,
+                                                                            uint32_t* __restrict__ counts, uint32_t* __restrict__ split_tiles) {
+    __shared__ uint32_t cursor[64];
+    if (threadIdx.x < 64) cursor[threadIdx.x] = tmp[4 + 64 * blockIdx.x + threadIdx.x];
+    __syncthreads();
+    const unsigned long long granule = sched_granule(tmp, max_split);
+    int begin, end;
+    sched_share(n, begin, end);
+    for (int i = begin + (int)threadIdx.x; i < end; i += blockDim.x) {
+        int per_piece;
+        const uint32_t c = cost[i];
+        const int k = sched_split(c, granule, num_samples, per_piece);
+        const uint32_t first = atomicAdd(&cursor[sched_bucket(c / (uint32_t)k, sort)], (uint32_t)k);
         int slot = -1;
         if (k > 1) {
-            slot = (int)atomicAdd(&num_split, 1u);
+            slot = (int)atomicAdd(&counts[1], 1u);
             split_tiles[slot] = (uint32_t)i;
         }
         for (int j = 0; j < k; ++j) {
@@ -1311,10 +1342,7 @@ __global__ __launch_bounds__(1024) void pt_schedule_items_kernel(const uint32_t*
             it.scratch_slot = slot;
             items[first + (uint32_t)j] = it;
         }
-      }
     }
-    __syncthreads();
-    if (threadIdx.x == 0) counts[1] = num_split;
 }
 
 int window_tiles(const PtKernelParams& p) { return PT_TILES_ACROSS(p.win_w) * PT_TILES_ACROSS(p.win_h); }
@@ -1362,12 +1390,18 @@ hipError_t pt_launch_arith_selftest(unsigned long long* bad, hipStream_t stream)
     return hipGetLastError();
 }
 
-hipError_t pt_launch_schedule_items(const uint32_t* tile_cost, PtWorkItem* items, uint32_t* sched_counts, uint32_t* split_tiles, int num_tiles,
-                                    int num_samples, int max_split_tiles, hipStream_t stream) {
+hipError_t pt_launch_schedule_items(const uint32_t* tile_cost, PtWorkItem* items, uint32_t* sched_counts, uint32_t* split_tiles, uint32_t* sched_tmp,
+                                    int num_tiles, int num_samples, int max_split_tiles, hipStream_t stream) {
     if (num_tiles <= 0) return hipSuccess;
     static const int sort = getenv("PT_SCHED_SORT") ? atoi(getenv("PT_SCHED_SORT")) : 1;
-    hipLaunchKernelGGL(pt_schedule_items_kernel, dim3(1), dim3(1024), 0, stream, tile_cost, items, sched_counts, split_tiles, num_tiles,
-                       num_samples, max_split_tiles, sort);
+    hipError_t e = hipMemsetAsync(sched_tmp, 0, 4 * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    const dim3 grid(PT_SCHED_BLOCKS), block(PT_SCHED_THREADS);
+    hipLaunchKernelGGL(pt_sched_total_kernel, grid, block, 0, stream, tile_cost, num_tiles, sched_tmp);
+    hipLaunchKernelGGL(pt_sched_count_kernel, grid, block, 0, stream, tile_cost, num_tiles, num_samples, max_split_tiles, sort, sched_tmp);
+    hipLaunchKernelGGL(pt_sched_offsets_kernel, dim3(1), dim3(64), 0, stream, sched_tmp, sched_counts);
+    hipLaunchKernelGGL(pt_sched_scatter_kernel, grid, block, 0, stream, tile_cost, num_tiles, num_samples, max_split_tiles, sort, sched_tmp, items,
+                       sched_counts, split_tiles);
     return hipGetLastError();
 }
 
