@@ -111,9 +111,10 @@ typedef struct PtStats {
     uint64_t bvh_node_fetches; /* LBVH traversal: 64-byte node records fetched, counted once per WAVE (the walk is per wave) */
     uint64_t bvh_triangle_fetches; /* LBVH traversal: 64-byte triangle records (+4-byte id) fetched, once per wave */
     uint64_t grid_triangle_tests; /* direction grid: triangle tests, counted per ray */
-    uint64_t grid_entries;     /* direction grid as currently built: total length of its cell lists (0 = not built) */
-    uint32_t dispatches;       /* render-kernel launches */
-    float last_dispatch_ms;    /* duration of the most recent render kernel; 0 unless timing is enabled */
+    uint64_t grid_entries;     /* direction grid as currently built: (cell, triangle) entries over all cells (0 = not built) */
+    uint32_t dispatches;       /* pt_dispatch calls */
+    float last_dispatch_ms;    /* device time of the most recent pt_dispatch (scheduler, render and fold kernels);
+                                  0 unless timing is enabled */
     double total_dispatch_ms;  /* sum over dispatches since the last reset; 0 unless timing is enabled */
 } PtStats;
 
@@ -209,7 +210,10 @@ PtStatus pt_set_uniforms(PtContext* ctx, const PtUniforms* uniforms);
  * Renders `num_samples` consecutive passes u_Samples = first_sample, first_sample + stride, ... for every pixel of
  * the window and leaves the result in the current image, exactly as that many reference frames would (the
  * running mean is carried in registers between passes instead of through memory). num_samples = 1, stride = 1
- * is one reference frame. first_sample is 1-based (PathTracer.cpp:1305,1378). */
+ * is one reference frame. first_sample is 1-based (PathTracer.cpp:1305,1378).
+ * Not fully asynchronous: when the work list is rebuilt (second dispatch of a view, then about every 16th; never for
+ * num_samples = 1) two counters are read back, which waits for the stream, and scratch memory may be allocated. A
+ * dispatch of 32 samples or more that has no tile costs to go by is issued as two launches (8 samples, then the rest). */
 PtStatus pt_dispatch(PtContext* ctx, int32_t first_sample, int32_t num_samples, int32_t stride);
 /* Replaces glFinish (PathTracer.cpp:1403): waits for the stream and reports any kernel fault. */
 PtStatus pt_finish(PtContext* ctx);
@@ -225,7 +229,8 @@ PtStatus pt_present_rgba8(PtContext* ctx, uint8_t* dst);
 /* Device address of the current image (for hosts that consume it on the device). */
 PtStatus pt_current_image(PtContext* ctx, void** out_device_ptr);
 /* Traces primary rays only and copies per-pixel closest-hit ids (int32; -1 = miss; sphere id for
- * PT_PROGRAM_WORLD, triangle id for PT_PROGRAM_MESH) and hit distances (1e38 on a miss). Either may be NULL. */
+ * PT_PROGRAM_WORLD, triangle id for PT_PROGRAM_MESH) and hit distances (1e38 on a miss). Either may be NULL. Only the
+ * pixels of the window (and of this context's row blocks, pt_set_row_interleave) are filled in. */
 PtStatus pt_readback_primary(PtContext* ctx, int32_t* ids, float* t);
 PtStatus pt_enable_timing(PtContext* ctx, int32_t enabled);
 PtStatus pt_get_stats(PtContext* ctx, PtStats* out);
