@@ -129,6 +129,10 @@ def main():
     else:
         first, stride, count = ptdist.sample_indices(rank, world, spp * world)
     tracer.enable_timing(True)
+    # the exchange of a frame's sums runs beside the rendering of the next frame (PT_BENCH_OVERLAP=0: in line, as one step)
+    merger = None
+    if sample_split and os.environ.get("PT_BENCH_OVERLAP", "1") != "0":
+        merger = ptdist.OverlappedSampleMerge(image, spp * world)
 
     def step():
         with torch.cuda.stream(stream):
@@ -136,12 +140,17 @@ def main():
             if not sample_split and not tile_split:
                 image[..., 3] = 1.0
             tracer.dispatch(first, count, stride)
-            if sample_split:
+            if merger is not None:
+                merger.submit(image)
+            elif sample_split:
                 ptdist.merge_sample_split(image, spp * world)
             elif tile_split:
                 ptdist.merge_tile_split(image, H)   # rows of other ranks are zero here: the sum moves bytes, nothing else
 
     def fence():
+        if merger is not None:
+            with torch.cuda.stream(stream):
+                merger.finish()   # the last frame's exchange belongs to the timed region
         stream.synchronize()
         torch.cuda.synchronize(device)
         if world > 1:

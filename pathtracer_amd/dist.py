@@ -58,6 +58,52 @@ def merge_sample_split(sum_image, total_samples, group=None):
     return sum_image
 
 
+class OverlappedSampleMerge:
+    """Sample-split merge that runs beside the rendering of the NEXT frame.
+
+    `submit(sum_image)` copies this rank's running sums into a staging image and starts the all-reduce of that copy
+    without waiting for it (RCCL runs it on its own stream, ordered after the copy), so the caller can clear
+    `sum_image` and render the next frame at once; the exchange of one frame (a few hundred microseconds for a 1080p
+    RGBA32F image over xGMI) hides behind the milliseconds of the next. `finish()` waits for the exchange in flight,
+    scales the sums to the mean and returns the merged image; `submit` calls it first, so one staging image is enough.
+    Device images over a backend that reduces on the host (gloo rehearsals on a GPU) are served synchronously. Call both under the stream the
+    renderer uses."""
+
+    def __init__(self, like, total_samples, group=None, force_async=False):
+        self.merged = torch.empty_like(like)
+        self.total_samples = float(total_samples)
+        self.group = group
+        self.work = None
+        self.scaled = True
+        on = dist.is_available() and dist.is_initialized()
+        # device images need a backend that reduces device memory (RCCL); host images go through any backend
+        direct = on and (not like.is_cuda or dist.get_backend(group) == "nccl")
+        self.asynchronous = bool(direct and (dist.get_world_size(group) > 1 or force_async))
+
+    def _scale(self):
+        if not self.scaled:
+            self.merged.mul_(1.0 / self.total_samples)
+            self.merged[..., 3] = 1.0
+            self.scaled = True
+
+    def submit(self, sum_image):
+        self.finish()
+        self.merged.copy_(sum_image)
+        self.scaled = False
+        if self.asynchronous:
+            self.work = dist.all_reduce(self.merged, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            _all_reduce_sum(self.merged, self.group)
+            self._scale()
+
+    def finish(self):
+        if self.work is not None:
+            self.work.wait()  # the current stream waits for the exchange; the host does not
+            self.work = None
+        self._scale()
+        return self.merged
+
+
 def merge_tile_split(image, height, block=16, group=None):
     """Every rank ends up with the full image: rows it does not own are zero before the call, so a sum all-reduce
     moves each row from its owner to everyone without changing a bit (x + 0 + ... + 0 is exact)."""

@@ -66,6 +66,17 @@ def _worker(rank, world, port, mode, out_dir):
         acc, _ = po.render_sum(scene, u, first, stride, count, threads=2)
         img = torch.from_numpy(acc)
         ptdist.merge_sample_split(img, total)
+    elif mode == "sample_overlapped":
+        # two frames (samples 1..6 and 7..12) through the merger that exchanges one frame while the next renders
+        merger = ptdist.OverlappedSampleMerge(torch.zeros(H, W, 4), total)
+        assert merger.asynchronous
+        for frame in range(2):
+            first, stride, count = ptdist.sample_indices(rank, world, total)
+            acc, _ = po.render_sum(scene, u, first + frame * total, stride, count, threads=2)
+            sums = torch.from_numpy(acc)
+            merger.submit(sums)
+            sums.zero_()   # the renderer's image is free again at once
+        img = merger.finish().clone()   # frame 1; frame 0 was returned by the finish() inside the second submit
     else:
         rgba = np.zeros((H, W, 4), np.float32)
         rgba[..., 3] = 1.0
@@ -79,7 +90,7 @@ def _worker(rank, world, port, mode, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["sample", "tile"])
+@pytest.mark.parametrize("mode", ["sample", "sample_overlapped", "tile"])
 def test_two_ranks_reproduce_single_process(tmp_path, mode):
     import pt_oracle as po
     from helpers import load_case
@@ -88,7 +99,11 @@ def test_two_ranks_reproduce_single_process(tmp_path, mode):
     fx = load_case("cornell_geo_128")
     scene = po.Scene(fx["vertices"], fx["indices"], fx["spheres"], fx["materials"])
     u = po.uniforms(fx["camera"], 128, 128, len(fx["indices"]), 10, 1, 1)
-    ref, _ = po.render(scene, u, 1, 6, threads=8)
+    if mode == "sample_overlapped":   # its result is the second frame: samples 7..12 on their own
+        acc, _ = po.render_sum(scene, u, 7, 1, 6, threads=8)
+        ref = acc * np.float32(1.0 / 6.0)
+    else:
+        ref, _ = po.render(scene, u, 1, 6, threads=8)
     outs = [np.load(tmp_path / f"{mode}_{r}.npy") for r in range(world)]
     assert np.array_equal(outs[0], outs[1]), "every rank holds the merged image"
     if mode == "tile":

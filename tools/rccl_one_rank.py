@@ -41,6 +41,33 @@ def main():
         dist.barrier()
         assert torch.equal(image, before * (1.0 / 32.0)), "all-reduce over one rank changed the image"
     print(f"ok: 5 steps of render + RCCL all-reduce + barrier on one rank in {time.perf_counter() - t0:.3f} s")
+    # the overlapped form bench.py uses: the exchange of frame k is in flight while frame k + 1 renders
+    from pathtracer_amd import dist as ptdist
+    merger = ptdist.OverlappedSampleMerge(image, 32, force_async=True)
+    assert merger.asynchronous
+    expected = []
+    t1 = time.perf_counter()
+    for step in range(6):
+        with torch.cuda.stream(stream):
+            image.zero_()
+            t.dispatch(1 + step, 32, 1)          # another set of samples every frame, so frames differ
+            expected.append(image.clone())
+            if step > 0:
+                got = merger.finish().clone()    # frame step - 1, merged
+                want = expected[step - 1] * (1.0 / 32.0)
+                want[..., 3] = 1.0
+                stream.synchronize()
+                assert torch.equal(got, want), f"overlapped merge of frame {step - 1} differs"
+            merger.submit(image)
+    with torch.cuda.stream(stream):
+        last = merger.finish()
+    stream.synchronize()
+    torch.cuda.synchronize(device)
+    dist.barrier()
+    want = expected[-1] * (1.0 / 32.0)
+    want[..., 3] = 1.0
+    assert torch.equal(last, want), "overlapped merge of the last frame differs"
+    print(f"ok: 6 frames with the exchange overlapped in {time.perf_counter() - t1:.3f} s")
     t.close()
     dist.destroy_process_group()
 
