@@ -774,7 +774,10 @@ PtStatus pt_target_create(PtContext* ctx, int32_t width, int32_t height) {
     ctx->image_owned = true;
     PT_HIP_TRY(hipMalloc(&ctx->d_image[1], bytes));
     s = target_common(ctx, width, height);
-    if (s != PT_OK) return s;
+    if (s != PT_OK) {
+        free_target(ctx);  // no half-made target: later calls report "no accumulation target"
+        return s;
+    }
     return pt_target_clear(ctx);
 }
 
@@ -789,7 +792,9 @@ PtStatus pt_target_bind_external(PtContext* ctx, void* rgba_a, void* rgba_b, int
     ctx->d_image[0] = (float*)rgba_a;
     ctx->d_image[1] = (float*)rgba_b;
     ctx->image_owned = false;
-    return target_common(ctx, width, height);
+    s = target_common(ctx, width, height);
+    if (s != PT_OK) free_target(ctx);  // (the caller's images are not freed: image_owned is false)
+    return s;
 }
 
 PtStatus pt_target_clear(PtContext* ctx) {
