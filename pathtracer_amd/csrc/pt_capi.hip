@@ -88,8 +88,10 @@ struct PtContext {
     bool grid_wanted = false;   // pt_build_accel was called for this mesh
     bool grid_built = false;
     int32_t grid_res_override = 0;
+    bool grid_res_reduced = false;  // the preferred resolution gave lists too long for this mesh
     uint64_t grid_entries = 0;
-    unsigned long long* d_grid_estimate = nullptr;
+    unsigned long long* d_grid_estimate = nullptr;   // scratch of the grid's count pass and its three-word summary
+    unsigned long long* h_grid_summary = nullptr;    // pinned host copy of the summary
 
     // target
     float* d_image[2] = {nullptr, nullptr};
@@ -235,35 +237,37 @@ PtStatus build_grid(PtContext* ctx) {
     ctx->grid_built = false;
     // Resolution: the preferred one, halved while the lists could exceed 2^30 entries (4 GiB) -- many triangles that each
     // cover a large part of a fine grid. Below 32 cells per face edge the grid is given up; the other search modes remain.
-    if (!ctx->d_grid_estimate) PT_HIP_TRY(hipMalloc(&ctx->d_grid_estimate, sizeof(unsigned long long)));
-    int res = grid_resolution(ctx);
-    for (;; res /= 2) {
-        if (res < 32) return PT_OK;
-        unsigned long long bound = 0;
-        PT_HIP_TRY(pt_grid_estimate(ctx->d_tris, ctx->num_triangles, res, ctx->d_grid_estimate, ctx->stream));
-        PT_HIP_TRY(hipMemcpyAsync(&bound, ctx->d_grid_estimate, sizeof bound, hipMemcpyDeviceToHost, ctx->stream));
-        PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
-        if (bound < (1ull << 30)) break;
-    }
+    if (!ctx->d_grid_estimate) PT_HIP_TRY(hipMalloc(&ctx->d_grid_estimate, (2 * PT_GRID_BOUND_SLOTS + 4) * sizeof(unsigned long long)));
+    if (!ctx->h_grid_summary) PT_HIP_TRY(hipHostMalloc(&ctx->h_grid_summary, 4 * sizeof(unsigned long long)));  // pinned: one short copy per build
     PtGridBuild& g = ctx->grid;
-    const size_t cells = (size_t)6 * res * res;
-    if (g.res != res) {
-        free_grid(ctx);
-        g.res = res;
-        g.scan_tmp_bytes = pt_grid_scan_temp_bytes(cells);
-        PT_HIP_TRY(hipMalloc(&g.cell_count, (cells + 1) * sizeof(uint32_t)));
-        PT_HIP_TRY(hipMalloc(&g.cell_start, (cells + 1) * sizeof(uint32_t)));
-        PT_HIP_TRY(hipMalloc(&g.cells, (cells + 1) * sizeof(uint32_t)));
-        PT_HIP_TRY(hipMalloc(&g.scan_tmp, g.scan_tmp_bytes ? g.scan_tmp_bytes : 16));
-        g.big_capacity = (uint32_t)std::min<size_t>((size_t)ctx->num_triangles * 6, (size_t)4 << 20);
-        PT_HIP_TRY(hipMalloc(&g.big_jobs, (size_t)g.big_capacity * sizeof(uint32_t)));
-        PT_HIP_TRY(hipMalloc(&g.big_count, sizeof(uint32_t)));
-    }
-    PT_HIP_TRY(pt_grid_count(g, ctx->d_tris, ctx->num_triangles, ctx->stream));
     uint32_t total = 0, entries = 0;  // list words needed (cells with two or more triangles); all (cell, triangle) entries
-    PT_HIP_TRY(hipMemcpyAsync(&total, g.cell_start + cells, sizeof total, hipMemcpyDeviceToHost, ctx->stream));
-    PT_HIP_TRY(hipMemcpyAsync(&entries, g.cells + cells, sizeof entries, hipMemcpyDeviceToHost, ctx->stream));
-    PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    size_t cells = 0;
+    // (a mesh that needed a coarser grid once keeps it until the next upload, so camera moves do not reallocate)
+    for (int res = (ctx->grid_res_reduced && g.res > 0) ? g.res : grid_resolution(ctx);; res /= 2, ctx->grid_res_reduced = true) {
+        if (res < 32) return PT_OK;
+        cells = (size_t)6 * res * res;
+        if (g.res != res) {
+            free_grid(ctx);
+            g.res = res;
+            g.scan_tmp_bytes = pt_grid_scan_temp_bytes(cells);
+            PT_HIP_TRY(hipMalloc(&g.cell_count, (cells + 1) * sizeof(uint32_t)));
+            PT_HIP_TRY(hipMalloc(&g.cell_start, (cells + 1) * sizeof(uint32_t)));
+            PT_HIP_TRY(hipMalloc(&g.cells, (cells + 1) * sizeof(uint32_t)));
+            PT_HIP_TRY(hipMalloc(&g.scan_tmp, g.scan_tmp_bytes ? g.scan_tmp_bytes : 16));
+            g.big_capacity = (uint32_t)std::min<size_t>((size_t)ctx->num_triangles * 6, (size_t)4 << 20);
+            PT_HIP_TRY(hipMalloc(&g.big_jobs, (size_t)g.big_capacity * sizeof(uint32_t)));
+            PT_HIP_TRY(hipMalloc(&g.big_count, sizeof(uint32_t)));
+        }
+        // the count pass also sums the bound and stops short of the large jobs when it is exceeded
+        unsigned long long* summary = ctx->d_grid_estimate + 2 * PT_GRID_BOUND_SLOTS;
+        PT_HIP_TRY(pt_grid_count(g, ctx->d_tris, ctx->num_triangles, ctx->d_grid_estimate, summary, ctx->stream));
+        PT_HIP_TRY(hipMemcpyAsync(ctx->h_grid_summary, summary, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+        PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        const unsigned long long bound = ctx->h_grid_summary[0];
+        entries = (uint32_t)std::min<unsigned long long>(ctx->h_grid_summary[1], 0xffffffffull);
+        total = (uint32_t)ctx->h_grid_summary[2];
+        if (bound < PT_GRID_MAX_LIST_BOUND) break;
+    }
     if ((size_t)total > g.list_capacity) {
         if (g.list) (void)hipFree(g.list);
         g.list = nullptr;
@@ -282,6 +286,7 @@ void free_mesh(PtContext* ctx) {
     free_bvh(ctx);
     free_grid(ctx);
     ctx->grid_wanted = false;
+    ctx->grid_res_reduced = false;
     float** f[] = {&ctx->d_vertices, &ctx->d_tris, &ctx->d_vnormals, &ctx->d_gnormals, &ctx->d_cull, &ctx->d_tris_abs, &ctx->d_tris_live, &ctx->d_tris_grid};
     if (ctx->d_live_count) (void)hipFree(ctx->d_live_count);
     ctx->d_live_count = nullptr;
@@ -530,6 +535,7 @@ PtStatus pt_destroy(PtContext* ctx) {
     if (ctx->d_sphere_recs) (void)hipFree(ctx->d_sphere_recs);
     if (ctx->d_materials) (void)hipFree(ctx->d_materials);
     if (ctx->d_grid_estimate) (void)hipFree(ctx->d_grid_estimate);
+    if (ctx->h_grid_summary) (void)hipHostFree(ctx->h_grid_summary);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);

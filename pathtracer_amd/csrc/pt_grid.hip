@@ -62,14 +62,8 @@ struct FaceJob {
     bool use_edges;
 };
 
-__device__ bool setup_job(const float4* __restrict__ tris, int i, int f, int res, FaceJob& job) {
-    const float4 r0 = tris[4 * (size_t)i], r1 = tris[4 * (size_t)i + 1], r2 = tris[4 * (size_t)i + 2], r3 = tris[4 * (size_t)i + 3];
-    if (!(r3.x > 0.0f)) return false;  // e2r <= 0 (or NaN): no ray from the origin can be accepted
-    // record: e1.xyz e2.x | e2.yz ap.xy | ap.z r.xyz | e2r - - id
-    P3 A, B, C;
-    A.x = -r1.z; A.y = -r1.w; A.z = -r2.x;
-    B.x = A.x + r0.x; B.y = A.y + r0.y; B.z = A.z + r0.z;
-    C.x = A.x + r0.w; C.y = A.y + r1.x; C.z = A.z + r1.y;
+// The triangle (A, A + e1, A + e2 relative to the ray origin) on face f.
+__device__ bool setup_face(P3 A, P3 B, P3 C, P3 e1, P3 e2, int f, int res, FaceJob& job) {
     P3 pa[kMaxPoly], pb[kMaxPoly];
     pa[0] = to_face(A, f); pa[1] = to_face(B, f); pa[2] = to_face(C, f);
     // cheap reject: the whole triangle behind the face's apex plane
@@ -97,8 +91,8 @@ __device__ bool setup_job(const float4* __restrict__ tris, int i, int f, int res
     // plane through the origin and one edge; the computed side of a direction is off by a few eps x S over the doubled
     // area of the triangle (origin, edge), S bounding the magnitudes that enter the sums. That is ~1e-7 rad for ordinary
     // views and grows only when an edge points at the origin. x4: radians -> face coordinates, both axes.
-    const float lA = sqrtf(A.x * A.x + A.y * A.y + A.z * A.z), l1 = sqrtf(r0.x * r0.x + r0.y * r0.y + r0.z * r0.z),
-                l2 = sqrtf(r0.w * r0.w + r1.x * r1.x + r1.y * r1.y);
+    const float lA = sqrtf(A.x * A.x + A.y * A.y + A.z * A.z), l1 = sqrtf(e1.x * e1.x + e1.y * e1.y + e1.z * e1.z),
+                l2 = sqrtf(e2.x * e2.x + e2.y * e2.y + e2.z * e2.z);
     auto cross_len = [](P3 a, P3 b) {
         const float x = a.y * b.z - a.z * b.y, y = a.z * b.x - a.x * b.z, z = a.x * b.y - a.y * b.x;
         return sqrtf(x * x + y * y + z * z);
@@ -121,6 +115,39 @@ __device__ bool setup_job(const float4* __restrict__ tris, int i, int f, int res
     job.m = m;
     job.slack = slack;
     return true;
+}
+
+// record: e1.xyz e2.x | e2.yz ap.xy | ap.z r.xyz | e2r - - id
+struct TriCorners { P3 A, B, C, e1, e2; };
+__device__ __forceinline__ bool load_corners(const float4* __restrict__ tris, int i, TriCorners& t) {
+    const float4 r0 = tris[4 * (size_t)i], r1 = tris[4 * (size_t)i + 1], r2 = tris[4 * (size_t)i + 2], r3 = tris[4 * (size_t)i + 3];
+    if (!(r3.x > 0.0f)) return false;  // e2r <= 0 (or NaN): no ray from the origin can be accepted
+    t.A.x = -r1.z; t.A.y = -r1.w; t.A.z = -r2.x;
+    t.e1.x = r0.x; t.e1.y = r0.y; t.e1.z = r0.z;
+    t.e2.x = r0.w; t.e2.y = r1.x; t.e2.z = r1.y;
+    t.B.x = t.A.x + r0.x; t.B.y = t.A.y + r0.y; t.B.z = t.A.z + r0.z;
+    t.C.x = t.A.x + r0.w; t.C.y = t.A.y + r1.x; t.C.z = t.A.z + r1.y;
+    return true;
+}
+
+// Is the triangle wholly outside one side plane of face f's (widened) pyramid? The same sums as the first clipping step
+// forms for each plane, on the three corners: if all three are negative for one plane nothing of the triangle is on this face.
+__device__ __forceinline__ bool outside_pyramid(const TriCorners& t, int f) {
+    const P3 a = to_face(t.A, f), b = to_face(t.B, f), c = to_face(t.C, f);
+    if (a.z <= 0.f && b.z <= 0.f && c.z <= 0.f) return true;
+    const float k = 1.0f + kPyramidSlack;
+    auto side = [k](P3 p, float nx, float ny) { return nx * p.x + ny * p.y + k * p.z; };
+    if (side(a, -1.f, 0.f) < 0.f && side(b, -1.f, 0.f) < 0.f && side(c, -1.f, 0.f) < 0.f) return true;
+    if (side(a, 1.f, 0.f) < 0.f && side(b, 1.f, 0.f) < 0.f && side(c, 1.f, 0.f) < 0.f) return true;
+    if (side(a, 0.f, -1.f) < 0.f && side(b, 0.f, -1.f) < 0.f && side(c, 0.f, -1.f) < 0.f) return true;
+    if (side(a, 0.f, 1.f) < 0.f && side(b, 0.f, 1.f) < 0.f && side(c, 0.f, 1.f) < 0.f) return true;
+    return false;
+}
+
+__device__ bool setup_job(const float4* __restrict__ tris, int i, int f, int res, FaceJob& job) {
+    TriCorners t;
+    if (!load_corners(tris, i, t)) return false;
+    return setup_face(t.A, t.B, t.C, t.e1, t.e2, f, res, job);
 }
 
 __device__ __forceinline__ bool cell_touched(const FaceJob& job, int res, int iu, int iv) {
@@ -170,36 +197,79 @@ struct ListNeed {
 
 constexpr int kInlineCells = 48;  // jobs covering more cells than this go to the queue of big jobs
 
-// One thread per (triangle, face). COUNT = true: cell_count[cell]++; false: the triangle is entered into the cell (enter()).
-// A job whose bounding box covers many cells is not walked here but queued for grid_bin_big (one workgroup per job).
+// The count pass refuses to walk once the bounding-box cells of all jobs together (an upper bound of the list length,
+// summed in 64 bits) reach this: the resolution is too fine for this mesh, and walking would take as long as the lists are.
+constexpr unsigned long long kMaxListBound = 1ull << 30;
+
+// One thread per triangle. COUNT = true: cell_count[cell]++ and bound[] += the job's bounding-box cells; false: the
+// triangle is entered into the cell (enter()). A job whose bounding box covers many cells is not walked here but queued
+// for grid_bin_big (one workgroup per job).
 template <bool COUNT>
 __global__ __launch_bounds__(128) void grid_bin_triangles(const float4* __restrict__ tris, int n, int res, uint32_t* __restrict__ cell_count,
                                                           const uint32_t* __restrict__ cell_start, uint32_t* __restrict__ list,
-                                                          uint32_t* __restrict__ cells_out, uint32_t* __restrict__ big_jobs, uint32_t* __restrict__ big_count, uint32_t big_capacity) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n * 6) return;
-    const int i = j / 6, f = j % 6;
-    FaceJob job;
-    if (!setup_job(tris, i, f, res, job)) return;
-    const int cells = (job.iu1 - job.iu0 + 1) * (job.iv1 - job.iv0 + 1);
-    if (cells > kInlineCells) {
-        const uint32_t slot = atomicAdd(big_count, 1u);
-        if (slot < big_capacity) {
-            big_jobs[slot] = (uint32_t)j;
-            return;
+                                                          uint32_t* __restrict__ cells_out, uint32_t* __restrict__ big_jobs, uint32_t* __restrict__ big_count, uint32_t big_capacity,
+                                                          unsigned long long* __restrict__ bound) {
+    // One thread per triangle, its six faces in turn: neighbouring triangles mostly fall on the same face, so the clipping
+    // (the expensive part) runs with most lanes of the wave instead of one lane in six.
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    TriCorners t;
+    const bool live = i < n && load_corners(tris, i, t);
+    unsigned long long my_cells = 0;
+    unsigned my_entries = 0;
+    for (int f = 0; f < 6; ++f) {
+        if (!live || outside_pyramid(t, f)) continue;
+        FaceJob job;
+        if (!setup_face(t.A, t.B, t.C, t.e1, t.e2, f, res, job)) continue;
+        const int cells = (job.iu1 - job.iu0 + 1) * (job.iv1 - job.iv0 + 1);
+        my_cells += (unsigned long long)cells;
+        if (cells > kInlineCells) {
+            const uint32_t slot = atomicAdd(big_count, 1u);
+            if (slot < big_capacity) {
+                big_jobs[slot] = (uint32_t)(i * 6 + f);
+                continue;
+            }
+            if (COUNT) {
+                atomicAdd(&bound[0], kMaxListBound);  // more big jobs than the queue holds: too fine a resolution as well
+                continue;
+            }
+            // (fill pass: the count pass queued the same jobs, so the queue cannot be full here)
         }
-        // queue full: walk it here after all
+        for (int iv = job.iv0; iv <= job.iv1; ++iv)
+            for (int iu = job.iu0; iu <= job.iu1; ++iu)
+                if (cell_touched(job, res, iu, iv)) {
+                    enter<COUNT>(res, f, iu, iv, (uint32_t)i, cell_count, cell_start, list, cells_out);
+                    ++my_entries;
+                }
     }
-    for (int iv = job.iv0; iv <= job.iv1; ++iv)
-        for (int iu = job.iu0; iu <= job.iu1; ++iu)
-            if (cell_touched(job, res, iu, iv)) enter<COUNT>(res, f, iu, iv, (uint32_t)i, cell_count, cell_start, list, cells_out);
+    if (COUNT) {
+        // (spread over PT_GRID_BOUND_SLOTS words: atomics on one address from every wave doubled the time of this kernel)
+        unsigned long long entries = my_entries;
+        for (int off = 32; off > 0; off >>= 1) {
+            my_cells += __shfl_down(my_cells, off);
+            entries += __shfl_down(entries, off);
+        }
+        const unsigned slot = (blockIdx.x * 2u + (threadIdx.x >> 6)) % PT_GRID_BOUND_SLOTS;
+        if ((threadIdx.x & 63) == 0 && my_cells) atomicAdd(&bound[slot], my_cells);
+        if ((threadIdx.x & 63) == 0 && entries) atomicAdd(&bound[PT_GRID_BOUND_SLOTS + slot], entries);
+    }
 }
 
 template <bool COUNT>
 __global__ __launch_bounds__(256) void grid_bin_big(const float4* __restrict__ tris, int res, uint32_t* __restrict__ cell_count,
                                                     const uint32_t* __restrict__ cell_start, uint32_t* __restrict__ list,
-                                                    uint32_t* __restrict__ cells_out, const uint32_t* __restrict__ big_jobs, const uint32_t* __restrict__ big_count, uint32_t big_capacity) {
+                                                    uint32_t* __restrict__ cells_out, const uint32_t* __restrict__ big_jobs, const uint32_t* __restrict__ big_count, uint32_t big_capacity,
+                                                    unsigned long long* __restrict__ bound) {
+    if (COUNT) {  // (the bound is complete: grid_bin_triangles ran before this kernel)
+        static_assert(PT_GRID_BOUND_SLOTS == 256, "one slot per thread of this block");
+        __shared__ unsigned long long partial[4];
+        unsigned long long sum = bound[threadIdx.x];
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
+        if ((threadIdx.x & 63) == 0) partial[threadIdx.x >> 6] = sum;
+        __syncthreads();
+        if (partial[0] + partial[1] + partial[2] + partial[3] >= kMaxListBound) return;
+    }
     const uint32_t queued = *big_count < big_capacity ? *big_count : big_capacity;
+    unsigned long long my_entries = 0;
     for (uint32_t slot = blockIdx.x; slot < queued; slot += gridDim.x) {
         const int j = (int)big_jobs[slot], i = j / 6, f = j % 6;
         FaceJob job;
@@ -207,42 +277,50 @@ __global__ __launch_bounds__(256) void grid_bin_big(const float4* __restrict__ t
         const int wu = job.iu1 - job.iu0 + 1, cells = wu * (job.iv1 - job.iv0 + 1);
         for (int c = threadIdx.x; c < cells; c += blockDim.x) {
             const int iu = job.iu0 + c % wu, iv = job.iv0 + c / wu;
-            if (cell_touched(job, res, iu, iv)) enter<COUNT>(res, f, iu, iv, (uint32_t)i, cell_count, cell_start, list, cells_out);
+            if (cell_touched(job, res, iu, iv)) {
+                enter<COUNT>(res, f, iu, iv, (uint32_t)i, cell_count, cell_start, list, cells_out);
+                ++my_entries;
+            }
         }
+    }
+    if (COUNT && blockIdx.x < queued) {  // (uniform per block: every wave of a block with work reports)
+        for (int off = 32; off > 0; off >>= 1) my_entries += __shfl_down(my_entries, off);
+        if ((threadIdx.x & 63) == 0 && my_entries) atomicAdd(&bound[PT_GRID_BOUND_SLOTS + (blockIdx.x * 4u + (threadIdx.x >> 6)) % PT_GRID_BOUND_SLOTS], my_entries);
     }
 }
 
-// Upper bound of the list length at resolution `res`: the bounding-box cells of every job, summed in 64 bits.
-__global__ __launch_bounds__(256) void grid_estimate(const float4* __restrict__ tris, int n, int res, unsigned long long* __restrict__ total) {
-    __shared__ unsigned long long partial[4];
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long cells = 0;
-    if (j < n * 6) {
-        FaceJob job;
-        if (setup_job(tris, j / 6, j % 6, res, job)) cells = (unsigned long long)(job.iu1 - job.iu0 + 1) * (unsigned long long)(job.iv1 - job.iv0 + 1);
+// summary[0] = upper bound of the list length, [1] = (cell, triangle) entries, [2] = list words needed
+__global__ __launch_bounds__(PT_GRID_BOUND_SLOTS) void grid_summary(const unsigned long long* __restrict__ slots, const uint32_t* __restrict__ list_need,
+                                                                   unsigned long long* __restrict__ summary) {
+    __shared__ unsigned long long partial[2][PT_GRID_BOUND_SLOTS / 64];
+    unsigned long long b = slots[threadIdx.x], e = slots[PT_GRID_BOUND_SLOTS + threadIdx.x];
+    for (int off = 32; off > 0; off >>= 1) {
+        b += __shfl_down(b, off);
+        e += __shfl_down(e, off);
     }
-    for (int off = 32; off > 0; off >>= 1) cells += __shfl_down(cells, off);
-    if ((threadIdx.x & 63) == 0) partial[threadIdx.x >> 6] = cells;
+    if ((threadIdx.x & 63) == 0) { partial[0][threadIdx.x >> 6] = b; partial[1][threadIdx.x >> 6] = e; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned long long sum = partial[0] + partial[1] + partial[2] + partial[3];
-        if (sum) atomicAdd(total, sum);
+        unsigned long long bs = 0, es = 0;
+        for (int w = 0; w < PT_GRID_BOUND_SLOTS / 64; ++w) { bs += partial[0][w]; es += partial[1][w]; }
+        summary[0] = bs;
+        summary[1] = es;
+        summary[2] = *list_need;
     }
 }
 
 template <bool COUNT>
-hipError_t bin_all(const PtGridBuild& g, const float* tris, int32_t n, hipStream_t stream) {
+hipError_t bin_all(const PtGridBuild& g, const float* tris, int32_t n, unsigned long long* bound, hipStream_t stream) {
     const size_t cells = (size_t)6 * g.res * g.res;
     hipError_t e = hipMemsetAsync(g.cell_count, 0, (cells + 1) * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(g.big_count, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
-    const int jobs = n * 6;
     const float4* t4 = reinterpret_cast<const float4*>(tris);
-    hipLaunchKernelGGL(grid_bin_triangles<COUNT>, dim3((jobs + 127) / 128), dim3(128), 0, stream, t4, n, g.res, g.cell_count, g.cell_start, g.list,
-                       g.cells, g.big_jobs, g.big_count, g.big_capacity);
+    hipLaunchKernelGGL(grid_bin_triangles<COUNT>, dim3((n + 127) / 128), dim3(128), 0, stream, t4, n, g.res, g.cell_count, g.cell_start, g.list,
+                       g.cells, g.big_jobs, g.big_count, g.big_capacity, bound);
     hipLaunchKernelGGL(grid_bin_big<COUNT>, dim3(2048), dim3(256), 0, stream, t4, g.res, g.cell_count, g.cell_start, g.list, g.cells, g.big_jobs,
-                       g.big_count, g.big_capacity);
+                       g.big_count, g.big_capacity, bound);
     return hipGetLastError();
 }
 
@@ -250,33 +328,23 @@ hipError_t bin_all(const PtGridBuild& g, const float* tris, int32_t n, hipStream
 
 size_t pt_grid_scan_temp_bytes(size_t cells) {
     size_t bytes = 0;
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)(cells + 1), nullptr);
-    size_t bytes2 = 0;
     hipcub::TransformInputIterator<uint32_t, ListNeed, const uint32_t*> need((const uint32_t*)nullptr, ListNeed());
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes2, need, (uint32_t*)nullptr, (int)(cells + 1), nullptr);
-    return bytes > bytes2 ? bytes : bytes2;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, need, (uint32_t*)nullptr, (int)(cells + 1), nullptr);
+    return bytes;
 }
 
-hipError_t pt_grid_estimate(const float* tris, int32_t n, int res, unsigned long long* total, hipStream_t stream) {
-    hipError_t e = hipMemsetAsync(total, 0, sizeof(unsigned long long), stream);
-    if (e != hipSuccess) return e;
-    const int jobs = n * 6;
-    hipLaunchKernelGGL(grid_estimate, dim3((jobs + 255) / 256), dim3(256), 0, stream, reinterpret_cast<const float4*>(tris), n, res, total);
-    return hipGetLastError();
-}
-
-hipError_t pt_grid_count(const PtGridBuild& g, const float* tris, int32_t n, hipStream_t stream) {
+hipError_t pt_grid_count(const PtGridBuild& g, const float* tris, int32_t n, unsigned long long* slots, unsigned long long* summary, hipStream_t stream) {
     const size_t cells = (size_t)6 * g.res * g.res;
-    hipError_t e = bin_all<true>(g, tris, n, stream);
+    hipError_t e = hipMemsetAsync(slots, 0, 2 * PT_GRID_BOUND_SLOTS * sizeof(unsigned long long), stream);
     if (e != hipSuccess) return e;
-    // all entries (cells[cells] <- their number; `cells` is rewritten by the fill pass), then the list space
+    e = bin_all<true>(g, tris, n, slots, stream);
+    if (e != hipSuccess) return e;
+    // list space of every cell (none for cells with fewer than two triangles)
     size_t bytes = g.scan_tmp_bytes;
-    e = hipcub::DeviceScan::ExclusiveSum(g.scan_tmp, bytes, g.cell_count, g.cells, (int)(cells + 1), stream);
-    if (e != hipSuccess) return e;
-    bytes = g.scan_tmp_bytes;
     hipcub::TransformInputIterator<uint32_t, ListNeed, const uint32_t*> need(g.cell_count, ListNeed());
     e = hipcub::DeviceScan::ExclusiveSum(g.scan_tmp, bytes, need, g.cell_start, (int)(cells + 1), stream);
     if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(grid_summary, dim3(1), dim3(PT_GRID_BOUND_SLOTS), 0, stream, slots, g.cell_start + cells, summary);
     return hipGetLastError();
 }
 
@@ -284,5 +352,5 @@ hipError_t pt_grid_fill(const PtGridBuild& g, const float* tris, int32_t n, hipS
     const size_t cells = (size_t)6 * g.res * g.res;
     hipError_t e = hipMemsetAsync(g.cells, 0xff, (cells + 1) * sizeof(uint32_t), stream);  // PT_GRID_EMPTY
     if (e != hipSuccess) return e;
-    return bin_all<false>(g, tris, n, stream);
+    return bin_all<false>(g, tris, n, nullptr, stream);
 }

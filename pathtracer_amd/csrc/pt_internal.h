@@ -88,10 +88,14 @@ struct PtGridBuild {
     uint32_t big_capacity;
 };
 size_t pt_grid_scan_temp_bytes(size_t cells);
-// *total <- an upper bound of the list length at resolution res (bounding-box cells of every triangle and face)
-hipError_t pt_grid_estimate(const float* tris, int32_t n, int res, unsigned long long* total, hipStream_t stream);
-// counts the entries of every cell; afterwards cells[6*res*res] = all entries, cell_start[6*res*res] = the list length needed
-hipError_t pt_grid_count(const PtGridBuild& g, const float* tris, int32_t n, hipStream_t stream);
+// Counts the entries of every cell; afterwards cell_start[6*res*res] = the list length needed and summary[0..2] = an upper
+// bound of the list length (bounding-box cells of every triangle and face), the (cell, triangle) entries, the list words
+// needed. A bound of PT_GRID_MAX_LIST_BOUND or more means the resolution is too fine for this mesh: the large jobs were
+// then not walked and the counts are not usable. slots: 2 * PT_GRID_BOUND_SLOTS words of device scratch.
+#define PT_GRID_MAX_LIST_BOUND (1ull << 30)
+#define PT_GRID_BOUND_SLOTS 256
+hipError_t pt_grid_count(const PtGridBuild& g, const float* tris, int32_t n, unsigned long long* slots, unsigned long long* summary,
+                         hipStream_t stream);
 // fills cells and list (capacity must cover cell_start[6*res*res])
 hipError_t pt_grid_fill(const PtGridBuild& g, const float* tris, int32_t n, hipStream_t stream);
 

@@ -277,19 +277,23 @@ def test_direction_grid_with_lists_that_would_not_fit():
         t.target_create(W, H)
         t.set_uniforms(cam, nt, 10)
         t.build_accel()
-        out = {}
-        for name, mode in (("auto", capi.ACCEL_AUTO), ("brute", capi.ACCEL_BRUTE)):
-            t.set_accel_mode(mode)
-            t.target_clear()
-            ids, ts = t.readback_primary()
-            t.dispatch(1, 3, 1)
-            t.finish()
-            out[name] = (ids, ts, t.readback())
-        st = t.stats()
-        assert st["grid_entries"] < (1 << 30)
-        assert np.array_equal(out["auto"][0], out["brute"][0])
-        assert n_bit_mismatch(out["auto"][1], out["brute"][1]) == 0
-        assert n_bit_mismatch(out["auto"][2], out["brute"][2]) == 0
-        assert (out["brute"][0] >= 0).mean() > 0.9
+        # the second camera position rebuilds the grid at the resolution the first one settled on
+        for eye in ((0.0, 0.0, 0.0), (0.05, -0.1, 0.02)):
+            cam = po.camera(90.0, W, H, eye, (0.2, 0.1, 1.0), (0, 1, 0))
+            t.set_uniforms(cam, nt, 10)
+            out = {}
+            for name, mode in (("auto", capi.ACCEL_AUTO), ("brute", capi.ACCEL_BRUTE)):
+                t.set_accel_mode(mode)
+                t.target_clear()
+                ids, ts = t.readback_primary()
+                t.dispatch(1, 3, 1)
+                t.finish()
+                out[name] = (ids, ts, t.readback())
+            st = t.stats()
+            assert st["grid_entries"] < (1 << 30)
+            assert np.array_equal(out["auto"][0], out["brute"][0])
+            assert n_bit_mismatch(out["auto"][1], out["brute"][1]) == 0
+            assert n_bit_mismatch(out["auto"][2], out["brute"][2]) == 0
+            assert (out["brute"][0] >= 0).mean() > 0.9
     finally:
         t.close()
