@@ -269,13 +269,19 @@ __global__ __launch_bounds__(256) void grid_bin_big(const float4* __restrict__ t
         if (partial[0] + partial[1] + partial[2] + partial[3] >= kMaxListBound) return;
     }
     const uint32_t queued = *big_count < big_capacity ? *big_count : big_capacity;
+    if (queued == 0u) return;
+    // Few jobs (a small mesh seen from close by: 36 triangles make about a hundred jobs of up to a whole face each): the
+    // cells of a job are shared out over `parts` workgroups, so that the launch still fills the device.
+    const uint32_t parts = queued < gridDim.x ? gridDim.x / queued : 1u;
+    const uint32_t part = blockIdx.x / queued;
+    if (parts > 1u && part >= parts) return;
     unsigned long long my_entries = 0;
-    for (uint32_t slot = blockIdx.x; slot < queued; slot += gridDim.x) {
+    for (uint32_t slot = parts > 1u ? blockIdx.x % queued : blockIdx.x; slot < queued; slot += gridDim.x) {
         const int j = (int)big_jobs[slot], i = j / 6, f = j % 6;
         FaceJob job;
         if (!setup_job(tris, i, f, res, job)) continue;  // (cannot fail: it succeeded when the job was queued)
         const int wu = job.iu1 - job.iu0 + 1, cells = wu * (job.iv1 - job.iv0 + 1);
-        for (int c = threadIdx.x; c < cells; c += blockDim.x) {
+        for (int c = (int)(part * blockDim.x + threadIdx.x); c < cells; c += (int)(parts * blockDim.x)) {
             const int iu = job.iu0 + c % wu, iv = job.iv0 + c / wu;
             if (cell_touched(job, res, iu, iv)) {
                 enter<COUNT>(res, f, iu, iv, (uint32_t)i, cell_count, cell_start, list, cells_out);
@@ -283,7 +289,7 @@ __global__ __launch_bounds__(256) void grid_bin_big(const float4* __restrict__ t
             }
         }
     }
-    if (COUNT && blockIdx.x < queued) {  // (uniform per block: every wave of a block with work reports)
+    if (COUNT) {
         for (int off = 32; off > 0; off >>= 1) my_entries += __shfl_down(my_entries, off);
         if ((threadIdx.x & 63) == 0 && my_entries) atomicAdd(&bound[PT_GRID_BOUND_SLOTS + (blockIdx.x * 4u + (threadIdx.x >> 6)) % PT_GRID_BOUND_SLOTS], my_entries);
     }
