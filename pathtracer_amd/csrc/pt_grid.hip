@@ -195,7 +195,11 @@ struct ListNeed {
     __host__ __device__ __forceinline__ uint32_t operator()(const uint32_t& count) const { return count >= 2u ? count : 0u; }
 };
 
-constexpr int kInlineCells = 48;  // jobs covering more cells than this go to the queue of big jobs
+// Jobs covering more cells than this go to the queue of big jobs. A small mesh queues every job: its few threads would
+// otherwise walk their cells one after the other on a nearly empty device (3,936 triangles: 0.20 ms for the two passes).
+constexpr int kInlineCells = 48;
+constexpr int kSmallMesh = 16384;
+__host__ __device__ inline int inline_cells(int n) { return n <= kSmallMesh ? 0 : kInlineCells; }
 
 // The count pass refuses to walk once the bounding-box cells of all jobs together (an upper bound of the list length,
 // summed in 64 bits) reach this: the resolution is too fine for this mesh, and walking would take as long as the lists are.
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(128) void grid_bin_triangles(const float4* __restri
         if (!setup_face(t.A, t.B, t.C, t.e1, t.e2, f, res, job)) continue;
         const int cells = (job.iu1 - job.iu0 + 1) * (job.iv1 - job.iv0 + 1);
         my_cells += (unsigned long long)cells;
-        if (cells > kInlineCells) {
+        if (cells > inline_cells(n)) {
             const uint32_t slot = atomicAdd(big_count, 1u);
             if (slot < big_capacity) {
                 big_jobs[slot] = (uint32_t)(i * 6 + f);
