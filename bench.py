@@ -110,6 +110,9 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    # Every step renders a frame from scratch: the camera-ray hits the library would keep from the previous dispatch of the
+    # same view are not carried from step to step (one query in about 400 per pixel and step, but a step stays self-contained).
+    os.environ.setdefault("PT_PRIMARY_CACHE", "0")
     trace("process group up")
     scene = SceneData(args.workload, args.width, args.height)
     W, H, spp = scene.width, scene.height, args.spp

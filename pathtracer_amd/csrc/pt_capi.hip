@@ -131,6 +131,16 @@ struct PtContext {
     int32_t list_samples = 0, list_age = 0;
     int64_t cost_samples = 0;   // samples per pixel behind the costs gathered since the list was built
     int64_t list_basis = 0;     // samples per pixel behind the costs the list was built from
+    // camera-ray hit per pixel (normal, triangle), kept from one dispatch to the next of the same view: the shader has no
+    // pixel jitter, so a frame loop of one sample per dispatch would evaluate the same query every frame
+    float4* d_primary_cache = nullptr;
+    bool primary_cache_enabled = true;   // PT_PRIMARY_CACHE=0 turns it off (for comparisons)
+    bool primary_cache_valid = false;
+    struct PrimaryCacheKey {
+        float camera[12];
+        int32_t num_triangles, win[4], rows[3], normal_mode, accel_mode;
+        uint32_t program;
+    } primary_cache_key{};
     int sched_mode = 2;             // 0 raster order, 1 cost-ordered tiles, 2 cost-ordered items with heavy tiles split by samples
 
     // uniforms
@@ -192,6 +202,9 @@ void free_target(PtContext* ctx) {
     if (ctx->d_sched_tmp) (void)hipFree(ctx->d_sched_tmp);
     ctx->d_sched_tmp = nullptr;
     if (ctx->d_split_tiles) (void)hipFree(ctx->d_split_tiles);
+    if (ctx->d_primary_cache) (void)hipFree(ctx->d_primary_cache);
+    ctx->d_primary_cache = nullptr;
+    ctx->primary_cache_valid = false;
     if (ctx->d_sample_scratch) (void)hipFree(ctx->d_sample_scratch);
     ctx->d_items = nullptr;
     ctx->d_sched_counts = ctx->d_split_tiles = nullptr;
@@ -316,6 +329,7 @@ PtStatus ensure_records(PtContext* ctx) {
     ctx->grid_valid = false;
     memcpy(ctx->records_ro, ro, sizeof ctx->records_ro);
     ctx->records_valid = true;
+    ctx->primary_cache_valid = false;
     ctx->list_valid = false;  // new mesh or camera position: the tile costs will change
     ctx->costs_stale = true;
     return PT_OK;
@@ -450,6 +464,7 @@ PtStatus fill_params(PtContext* ctx, PtKernelParams* p, const Program** prog_out
             PT_HIP_TRY(pt_launch_prepare_spheres(ctx->d_spheres, u.camera_position, ctx->d_sphere_recs, ctx->stream));
             memcpy(ctx->sphere_recs_ro, u.camera_position, sizeof ctx->sphere_recs_ro);
             ctx->sphere_recs_valid = true;
+            ctx->primary_cache_valid = false;
             ctx->list_valid = false;
             ctx->costs_stale = true;
         }
@@ -516,6 +531,7 @@ PtStatus pt_create(int32_t device, PtContext** out_ctx) {
     else if (sched && sched[0] == 't') ctx->sched_mode = 1;
     ctx->wave_slots = prop.multiProcessorCount * 4 * 8;
     if (const char* g = getenv("PT_AUTO_GRID")) ctx->auto_grid = g[0] != '0';
+    if (const char* g = getenv("PT_PRIMARY_CACHE")) ctx->primary_cache_enabled = g[0] != '0';
     if (const char* g = getenv("PT_GRID_RES")) ctx->grid_res_override = std::min(atoi(g), 8192);  // cell indices stay far below 2^32
     if (const char* l = getenv("PT_LANE_WALK")) ctx->lane_walk = l[0] != '0';
     if (const char* l = getenv("PT_LANE_STACK_LIMIT")) ctx->lane_stack_limit = std::max(0, std::min(PT_LANE_STACK, atoi(l)));
@@ -765,6 +781,8 @@ static PtStatus target_common(PtContext* ctx, int32_t width, int32_t height) {
     PT_HIP_TRY(hipMalloc(&ctx->d_sched_counts, 2 * sizeof(uint32_t)));
     PT_HIP_TRY(hipMalloc(&ctx->d_sched_tmp, PT_SCHED_TMP_WORDS * sizeof(uint32_t)));
     PT_HIP_TRY(hipMalloc(&ctx->d_split_tiles, (size_t)PT_MAX_SPLIT_FACTOR * ctx->wave_slots * sizeof(uint32_t)));
+    PT_HIP_TRY(hipMalloc(&ctx->d_primary_cache, n * sizeof(float4)));
+    ctx->primary_cache_valid = false;
     ctx->sched_have_cost = false;
     return PT_OK;
 }
@@ -972,6 +990,25 @@ PtStatus dispatch_range(PtContext* ctx, int32_t first_sample, int32_t num_sample
         ctx->cost_samples += num_samples;
         memcpy(ctx->sched_win, ctx->win, sizeof ctx->win);
         ctx->sched_have_cost = true;
+    }
+    // Camera-ray hits of this view: read if an earlier dispatch left them, written otherwise (reference shading only; the
+    // materials mode also needs the distance).
+    const bool cache_usable = ctx->primary_cache_enabled && ctx->primary_reuse && p.depth > 0 &&
+                              (prog->kind == PT_PROGRAM_WORLD || ctx->shading_mode == PT_SHADE_REFERENCE);
+    if (cache_usable) {
+        PtContext::PrimaryCacheKey key;
+        memset(&key, 0, sizeof key);
+        memcpy(key.camera, p.ro, 12); memcpy(key.camera + 3, p.llc, 12); memcpy(key.camera + 6, p.hor, 12); memcpy(key.camera + 9, p.ver, 12);
+        key.num_triangles = p.num_triangles;
+        memcpy(key.win, ctx->win, sizeof key.win);
+        key.rows[0] = p.row_block; key.rows[1] = p.row_index; key.rows[2] = p.row_count;
+        key.normal_mode = p.normal_mode;
+        key.accel_mode = (int32_t)ctx->accel_mode;
+        key.program = prog->handle;
+        p.primary_cache = ctx->d_primary_cache;
+        p.primary_cache_valid = ctx->primary_cache_valid && memcmp(&key, &ctx->primary_cache_key, sizeof key) == 0;
+        ctx->primary_cache_key = key;
+        ctx->primary_cache_valid = true;  // (this dispatch writes every pixel of the window it does not read)
     }
     PT_HIP_TRY(pt_launch_render(p, (int)prog->kind, ctx->stream));
     ctx->current ^= 1;  // PathTracer.cpp:1493

@@ -174,6 +174,8 @@ struct PtKernelParams {
                                         // samples of split tiles, folded afterwards
     int32_t max_items, max_split_tiles; // launch sizes (upper bounds of the two counts)
     uint32_t* tile_cost;                // per tile: loop trips spent on it in this dispatch (scheduling hint), or null
+    float4* primary_cache;              // optional, one per pixel of the target: the camera ray's hit (normal.xyz, triangle index bits; < 0 = miss)
+    int32_t primary_cache_valid;        // 1: read it; 0: evaluate the camera ray and write it
     int32_t* out_ids;                   // primary pass only
     float* out_t;                       // primary pass only
 };

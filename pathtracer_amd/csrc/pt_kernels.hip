@@ -852,9 +852,22 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
     bool hit0 = false;
     if (reuse) {
         const bool want0 = remaining > 0;
-        if (KIND == 3 || want0) hit0 = intersect(ro0, rd0, want0, N0, t0, id0);
-        if (__builtin_amdgcn_ballot_w64(want0)) ++trips;
-        if (want0) { ++traced; ++rays; }  // ++rays: the first sample's camera-ray query; later samples count theirs when they start
+        if (!MATERIALS && p.primary_cache && p.primary_cache_valid) {
+            // an earlier dispatch of this same view left the pixel's camera-ray hit (normal, triangle) behind: frame
+            // loops of one sample per dispatch do not evaluate it again
+            if (want0) {
+                const float4 c = p.primary_cache[pix];
+                N0 = V(c.x, c.y, c.z);
+                id0 = (int)__float_as_uint(c.w);
+                hit0 = id0 >= 0;
+                ++rays;
+            }
+        } else {
+            if (KIND == 3 || want0) hit0 = intersect(ro0, rd0, want0, N0, t0, id0);
+            if (__builtin_amdgcn_ballot_w64(want0)) ++trips;
+            if (want0) { ++traced; ++rays; }  // ++rays: the first sample's camera-ray query; later samples count theirs when they start
+            if (!MATERIALS && p.primary_cache && want0) p.primary_cache[pix] = make_float4(N0.x, N0.y, N0.z, __uint_as_float((uint32_t)id0));
+        }
     }
 
     // path state of the sample in flight

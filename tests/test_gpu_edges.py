@@ -249,3 +249,74 @@ def test_sphere_program_from_awkward_camera_positions(tracer, where):
         assert (ids >= 0).sum() > 20
     tracer.reset_stats()
     tracer.program_destroy(prog)
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_camera_ray_hits_kept_between_dispatches(kind):
+    """Frame loop of short dispatches: the camera ray's hit is kept from one dispatch to the next of the same view. Every
+    change of the view (camera direction, position, window, normal mode, search mode, triangle count, clear) must drop
+    or keep it correctly: the images equal those of a context with the mechanism switched off after every dispatch, the
+    reference's ray count is the same, fewer queries are evaluated, and the first frames equal the oracle's."""
+    import os
+    from pathtracer_amd import Tracer
+    fx = load_case("monkey_mesh_128")
+    W, H = 96, 64
+    old = os.environ.get("PT_PRIMARY_CACHE")
+    tracers = []
+    try:
+        for flag in ("1", "0"):
+            os.environ["PT_PRIMARY_CACHE"] = flag
+            tracers.append(Tracer(0))
+    finally:
+        if old is None:
+            del os.environ["PT_PRIMARY_CACHE"]
+        else:
+            os.environ["PT_PRIMARY_CACHE"] = old
+    try:
+        scene = u = None
+        for t in tracers:
+            _, scene, u = upload(t, fx, W, H, kind=kind)
+            t.build_accel()
+        ntri = len(fx["indices"])
+        cam_turned = po.camera(60.0, W, H, (0, 0, 0), (0.3, 0.1, 1), (0, 1, 0))     # same position, other direction
+        cam_moved = po.camera(60.0, W, H, (0.2, -0.1, 0.1), (0.3, 0.1, 1), (0, 1, 0))
+        sample = [1]
+
+        def frames(n, spp=1):
+            for _ in range(n):
+                for t in tracers:
+                    t.dispatch(sample[0], spp, 1)
+                    t.finish()
+                sample[0] += spp
+                a, b = tracers[0].readback(), tracers[1].readback()
+                assert n_bit_mismatch(a, b) == 0
+
+        frames(3)
+        ref, _ = po.render(scene, u, 1, 3)
+        assert n_bit_mismatch(tracers[0].readback(), ref) == 0
+        for change in ("turn", "move", "window", "normals", "accel", "fewer", "clear", "long"):
+            for t in tracers:
+                if change == "turn":
+                    t.set_uniforms(cam_turned, ntri, 10)
+                elif change == "move":
+                    t.set_uniforms(cam_moved, ntri, 10)
+                elif change == "window":
+                    t.set_window(10, 5, 50, 40)
+                elif change == "normals":
+                    t.set_normal_mode(1 - int(fx["normal_mode"]))
+                elif change == "accel":
+                    t.set_accel_mode(2 if kind == 1 else 0)
+                elif change == "fewer" and kind == 1:
+                    t.set_accel_mode(1)
+                    t.set_uniforms(cam_moved, ntri // 2, 10)
+                elif change == "clear":
+                    t.target_clear()
+            if change == "clear":
+                sample[0] = 1
+            frames(2, spp=40 if change == "long" else 1)
+        sa, sb = tracers[0].stats(), tracers[1].stats()
+        assert sa["rays"] == sb["rays"]
+        assert sa["rays_traced"] < sb["rays_traced"]
+    finally:
+        for t in tracers:
+            t.close()
