@@ -104,7 +104,8 @@ typedef struct PtStats {
     uint64_t rays;             /* closest-hit queries since the last pt_reset_stats(): one per bounce-loop iteration
                                   (the reference's definition, PathTracer.cpp:947; its GLSL mode never counts, :1315) */
     uint64_t rays_traced;      /* of those, the queries actually evaluated: with primary reuse (pt_set_primary_reuse) the
-                                  camera ray of a pixel is evaluated once per dispatch, not once per sample */
+                                  camera ray of a pixel is evaluated once per dispatch, not once per sample, and not at
+                                  all when an earlier dispatch of the same view left its answer */
     uint64_t samples;          /* pixel-samples (shader invocations) */
     uint64_t lane_slots;       /* 64 x the loop trips of every wave: rays / lane_slots is the fraction of SIMD lanes
                                   that did useful work (paths in one wave end at different times) */
@@ -213,7 +214,11 @@ PtStatus pt_set_uniforms(PtContext* ctx, const PtUniforms* uniforms);
  * is one reference frame. first_sample is 1-based (PathTracer.cpp:1305,1378).
  * Not fully asynchronous: when the work list is rebuilt (second dispatch of a view, then about every 16th; never for
  * num_samples = 1) two counters are read back, which waits for the stream, and scratch memory may be allocated. A
- * dispatch of 32 samples or more that has no tile costs to go by is issued as two launches (8 samples, then the rest). */
+ * dispatch of 32 samples or more that has no tile costs to go by is issued as two launches (8 samples, then the rest).
+ * The first dispatch after a change of mesh or camera position also rebuilds what depends on them (triangle records,
+ * direction grid: one more read-back). With primary reuse and PT_SHADE_REFERENCE the camera ray's hit of every pixel is
+ * kept (16 bytes per pixel) until uniforms, window, row partition, modes, program or mesh change, so single-sample
+ * dispatches of a standing camera do not evaluate it again; the images are the same either way. */
 PtStatus pt_dispatch(PtContext* ctx, int32_t first_sample, int32_t num_samples, int32_t stride);
 /* Replaces glFinish (PathTracer.cpp:1403): waits for the stream and reports any kernel fault. */
 PtStatus pt_finish(PtContext* ctx);
