@@ -76,6 +76,8 @@ struct PtContext {
     float mesh_extent = 0.f;        // largest absolute vertex coordinate
     PtShadingMode shading_mode = PT_SHADE_REFERENCE;
     bool records_valid = false;
+    bool static_records_valid = false;  // normals and origin-independent records: written after an upload, kept over camera moves
+    bool cull_valid = false;            // the cull records match records_ro
     bool live_valid = false, bvh_emit_valid = false, grid_valid = false;  // derived from the records, refreshed on use
     float records_ro[3] = {0, 0, 0};
     // LBVH (optional)
@@ -315,14 +317,22 @@ void free_mesh(PtContext* ctx) {
     ctx->max_material_id = -1;
     ctx->num_vertices = ctx->num_triangles = 0;
     ctx->records_valid = false;
+    ctx->static_records_valid = false;
+    ctx->cull_valid = false;
 }
 
 // Makes sure the per-triangle records match the current mesh and camera position.
 PtStatus ensure_records(PtContext* ctx) {
     const float* ro = ctx->uniforms.camera_position;
-    if (ctx->records_valid && memcmp(ro, ctx->records_ro, sizeof ctx->records_ro) == 0) return PT_OK;
+    // the cull records (a mode no default path reads) are only written while that mode is selected
+    const bool want_cull = ctx->accel_mode == PT_ACCEL_CULL;
+    if (ctx->records_valid && memcmp(ro, ctx->records_ro, sizeof ctx->records_ro) == 0 && (!want_cull || ctx->cull_valid)) return PT_OK;
+    // a camera move rewrites what depends on the ray origin; normals and origin-independent records only after an upload
     PT_HIP_TRY(pt_launch_prepare_triangles(ctx->d_vertices, ctx->d_indices, ctx->num_triangles, ro, ctx->d_tris,
-                                           ctx->d_vnormals, ctx->d_gnormals, ctx->d_cull, ctx->d_tris_abs, ctx->d_tris_grid, ctx->stream));
+                                           ctx->d_vnormals, ctx->d_gnormals, want_cull ? ctx->d_cull : nullptr, ctx->d_tris_abs, ctx->d_tris_grid,
+                                           ctx->static_records_valid ? 0 : 1, ctx->stream));
+    ctx->static_records_valid = true;
+    ctx->cull_valid = want_cull;
     // what is derived from the records is brought up to date when a dispatch actually uses it (ensure_* below)
     ctx->live_valid = false;
     ctx->bvh_emit_valid = false;

@@ -183,7 +183,7 @@ struct PtKernelParams {
 // Launchers (defined in pt_kernels.hip). All are asynchronous on `stream`.
 hipError_t pt_launch_prepare_triangles(const float* vertices, const uint32_t* indices, int32_t num_triangles,
                                        const float ro[3], float* tris, float* vnormals, float* gnormals, float* cull,
-                                       float* tris_abs, float* tris_grid, hipStream_t stream);
+                                       float* tris_abs, float* tris_grid, int write_static, hipStream_t stream);
 // recs (10 x 8 floats) <- the direction-independent terms of the sphere test for ray origin ro
 hipError_t pt_launch_prepare_spheres(const float* spheres, const float ro[3], float* recs, hipStream_t stream);
 // live <- the records of `tris` that any camera ray can hit at all (e2r > 0), order kept, zero padding after; *live_count <- how many

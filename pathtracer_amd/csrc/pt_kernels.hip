@@ -1047,7 +1047,10 @@ __global__ __launch_bounds__(256) void pt_prepare_triangles_kernel(const float* 
                                                                     float rox, float roy, float roz,
                                                                     float* __restrict__ tris, float* __restrict__ vnormals,
                                                                     float* __restrict__ gnormals, float* __restrict__ cull,
-                                                                    float* __restrict__ tris_abs, float* __restrict__ tris_grid) {
+                                                                    float* __restrict__ tris_abs, float* __restrict__ tris_grid,
+                                                                    int write_static) {
+    // write_static = 0: only what depends on the ray origin (tris, tris_grid, cull if given) -- a camera move;
+    // 1: also the arrays that depend on the mesh alone (tris_abs, vnormals, gnormals) -- after an upload
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float* pa = vertices + 6 * (size_t)indices[3 * i];
@@ -1057,30 +1060,32 @@ __global__ __launch_bounds__(256) void pt_prepare_triangles_kernel(const float* 
     const v3 e1 = b - a, e2 = c - a;
     const v3 ap = V(rox, roy, roz) - a;
     const v3 r = cross3(ap, e1);
-    float* t = tris + (size_t)i * PT_TRI_FLOATS;
-    t[0] = e1.x; t[1] = e1.y; t[2] = e1.z;
-    t[3] = e2.x; t[4] = e2.y; t[5] = e2.z;
-    t[6] = ap.x; t[7] = ap.y; t[8] = ap.z;
-    t[9] = r.x; t[10] = r.y; t[11] = r.z;
-    t[12] = dot3(e2, r);
-    t[13] = 0.f; t[14] = 0.f; t[15] = __uint_as_float((uint32_t)i);
-    // origin-independent record for rays with their own origins: a, e1, e2
-    float* ta = tris_abs + (size_t)i * PT_TRI_FLOATS;
-    ta[0] = a.x; ta[1] = a.y; ta[2] = a.z;
-    ta[3] = e1.x; ta[4] = e1.y; ta[5] = e1.z;
-    ta[6] = e2.x; ta[7] = e2.y; ta[8] = e2.z;
-    for (int k = 9; k < 16; ++k) ta[k] = 0.f;
-    float* vn = vnormals + (size_t)i * 9;
-    vn[0] = pa[3]; vn[1] = pa[4]; vn[2] = pa[5];
-    vn[3] = pb[3]; vn[4] = pb[4]; vn[5] = pb[5];
-    vn[6] = pc[3]; vn[7] = pc[4]; vn[8] = pc[5];
+    const float e2r = dot3(e2, r);
     const v3 g = normalize3(cross3(e1, e2));
-    gnormals[3 * (size_t)i] = g.x; gnormals[3 * (size_t)i + 1] = g.y; gnormals[3 * (size_t)i + 2] = g.z;
+    // records are 16 floats, 64-byte aligned: four 16-byte stores each
+    const float4 q0 = make_float4(e1.x, e1.y, e1.z, e2.x), q1 = make_float4(e2.y, e2.z, ap.x, ap.y), q2 = make_float4(ap.z, r.x, r.y, r.z);
+    float4* t = reinterpret_cast<float4*>(tris + (size_t)i * PT_TRI_FLOATS);
+    t[0] = q0; t[1] = q1; t[2] = q2;
+    t[3] = make_float4(e2r, 0.f, 0.f, __uint_as_float((uint32_t)i));
     // record of the direction-grid query: the same twelve words and e2r, then the geometric normal instead of the index
     // (the query knows the index from the cell), so a hit needs no further fetch
-    float* tg = tris_grid + (size_t)i * PT_TRI_FLOATS;
-    for (int k = 0; k < 13; ++k) tg[k] = t[k];
-    tg[13] = g.x; tg[14] = g.y; tg[15] = g.z;
+    float4* tg = reinterpret_cast<float4*>(tris_grid + (size_t)i * PT_TRI_FLOATS);
+    tg[0] = q0; tg[1] = q1; tg[2] = q2;
+    tg[3] = make_float4(e2r, g.x, g.y, g.z);
+    if (write_static) {
+        // origin-independent record for rays with their own origins: a, e1, e2
+        float4* ta = reinterpret_cast<float4*>(tris_abs + (size_t)i * PT_TRI_FLOATS);
+        ta[0] = make_float4(a.x, a.y, a.z, e1.x);
+        ta[1] = make_float4(e1.y, e1.z, e2.x, e2.y);
+        ta[2] = make_float4(e2.z, 0.f, 0.f, 0.f);
+        ta[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+        float* vn = vnormals + (size_t)i * 9;
+        vn[0] = pa[3]; vn[1] = pa[4]; vn[2] = pa[5];
+        vn[3] = pb[3]; vn[4] = pb[4]; vn[5] = pb[5];
+        vn[6] = pc[3]; vn[7] = pc[4]; vn[8] = pc[5];
+        gnormals[3 * (size_t)i] = g.x; gnormals[3 * (size_t)i + 1] = g.y; gnormals[3 * (size_t)i + 2] = g.z;
+    }
+    if (!cull) return;
 
     // Cull record: four unit normals of planes through the ray origin. A direction can only pass the exact test
     // when it lies on the inner side of the three edge planes (origin, two vertices) and sees the front of the
@@ -1363,10 +1368,10 @@ int window_tiles(const PtKernelParams& p) { return PT_TILES_ACROSS(p.win_w) * PT
 
 hipError_t pt_launch_prepare_triangles(const float* vertices, const uint32_t* indices, int32_t num_triangles,
                                        const float ro[3], float* tris, float* vnormals, float* gnormals, float* cull,
-                                       float* tris_abs, float* tris_grid, hipStream_t stream) {
+                                       float* tris_abs, float* tris_grid, int write_static, hipStream_t stream) {
     if (num_triangles <= 0) return hipSuccess;
     hipLaunchKernelGGL(pt_prepare_triangles_kernel, dim3((num_triangles + 255) / 256), dim3(256), 0, stream, vertices,
-                       indices, num_triangles, ro[0], ro[1], ro[2], tris, vnormals, gnormals, cull, tris_abs, tris_grid);
+                       indices, num_triangles, ro[0], ro[1], ro[2], tris, vnormals, gnormals, cull, tris_abs, tris_grid, write_static);
     return hipGetLastError();
 }
 
