@@ -7,7 +7,8 @@ A step = one pass of the hot path over one batch: `--spp` progressive samples of
 (default: cornell_box.obj at 1920x1080, 256 spp -- the configuration the metric is quoted on), rendered by ONE kernel
 launch with the scene and the accumulation image resident in HBM. With N > 1 every rank renders its own residue
 class of the sample indices (weak scaling: per-GPU work is fixed) into a running sum, and the sums are merged by one
-RCCL all-reduce per step inside the timed region.
+RCCL all-reduce per step inside the timed region; the exchange of a step runs beside the rendering of the next one, and
+the last step's exchange is waited for before the clock stops.
 
 Prints one JSON line on rank 0: whole-job Mrays/s (ray = one closest-hit query = one bounce-loop iteration, the
 reference's definition), the roofline of the render kernel and a CPU baseline from the oracle on the host cores.
@@ -255,7 +256,8 @@ def main():
                                    (f"{scene.num_triangles} triangles, closest hit through the direction grid (PT_ACCEL_AUTO)"
                                     if scene.program == 1 else "the reference's 10 spheres (IntersectWorld)"),
                        "parallelism": "single GPU" if world == 1 else (f"image rows in interleaved blocks of 16 over {world} GPUs, merged by an exact sum (RCCL all-reduce)"
-                                                                           if tile_split else f"sample split over {world} GPUs + RCCL all-reduce")},
+                                                                           if tile_split else f"sample split over {world} GPUs + RCCL all-reduce of the sums" +
+                                                                           (", overlapped with the next step's rendering" if merger is not None else ""))},
             "rays_definition": "closest-hit queries as the reference counts them: one per bounce-loop iteration of every sample "
                                "(PathTracer.cpp:947). The shader has no pixel jitter, so the first query of every sample of a pixel "
                                "is the same; it is evaluated once per dispatch and pixel and reused (bit-identical image). "
