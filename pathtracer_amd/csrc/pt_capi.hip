@@ -90,6 +90,7 @@ struct PtContext {
     bool grid_wanted = false;   // pt_build_accel was called for this mesh
     bool grid_built = false;
     int32_t grid_res_override = 0;
+    int32_t grid_queue_override = 0;  // PT_GRID_QUEUE=n (testing): capacity of the grid build's queue of large jobs
     bool grid_res_reduced = false;  // the preferred resolution gave lists too long for this mesh
     uint64_t grid_entries = 0;
     unsigned long long* d_grid_estimate = nullptr;   // scratch of the grid's count pass and its three-word summary
@@ -270,6 +271,7 @@ PtStatus build_grid(PtContext* ctx) {
             PT_HIP_TRY(hipMalloc(&g.cells, (cells + 1) * sizeof(uint32_t)));
             PT_HIP_TRY(hipMalloc(&g.scan_tmp, g.scan_tmp_bytes ? g.scan_tmp_bytes : 16));
             g.big_capacity = (uint32_t)std::min<size_t>((size_t)ctx->num_triangles * 6, (size_t)4 << 20);
+            if (ctx->grid_queue_override > 0) g.big_capacity = (uint32_t)ctx->grid_queue_override;
             PT_HIP_TRY(hipMalloc(&g.big_jobs, (size_t)g.big_capacity * sizeof(uint32_t)));
             PT_HIP_TRY(hipMalloc(&g.big_count, sizeof(uint32_t)));
         }
@@ -542,6 +544,7 @@ PtStatus pt_create(int32_t device, PtContext** out_ctx) {
     ctx->wave_slots = prop.multiProcessorCount * 4 * 8;
     if (const char* g = getenv("PT_AUTO_GRID")) ctx->auto_grid = g[0] != '0';
     if (const char* g = getenv("PT_PRIMARY_CACHE")) ctx->primary_cache_enabled = g[0] != '0';
+    if (const char* g = getenv("PT_GRID_QUEUE")) ctx->grid_queue_override = atoi(g);
     if (const char* g = getenv("PT_GRID_RES")) ctx->grid_res_override = std::min(atoi(g), 8192);  // cell indices stay far below 2^32
     if (const char* l = getenv("PT_LANE_WALK")) ctx->lane_walk = l[0] != '0';
     if (const char* l = getenv("PT_LANE_STACK_LIMIT")) ctx->lane_stack_limit = std::max(0, std::min(PT_LANE_STACK, atoi(l)));

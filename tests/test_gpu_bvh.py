@@ -297,3 +297,73 @@ def test_direction_grid_with_lists_that_would_not_fit():
             assert (out["brute"][0] >= 0).mean() > 0.9
     finally:
         t.close()
+
+
+@pytest.mark.parametrize("scene_kind", ["small_mesh", "soup"])
+def test_direction_grid_when_the_queue_of_large_jobs_overflows(scene_kind):
+    """The grid build queues (triangle, face) jobs that cover many cells; a queue that cannot hold them means the resolution
+    is too fine, and the build starts again at half of it, down to giving the grid up (PT_ACCEL_AUTO then uses another
+    search). Forced here with a small queue. small_mesh: monkeyhead2 queues every job (about 1,200) at any resolution, so
+    a queue of 16 never suffices and the grid is given up. soup: 20,000 triangles about a dozen cells across at the
+    preferred resolution (all large jobs there) fit a queue of 2,000 only on a coarser grid. The image equals the
+    all-triangles loop either way, also after a camera move (which rebuilds at the resolution settled on)."""
+    import os
+    from pathtracer_amd import Tracer, capi
+    W, H = 128, 96
+    if scene_kind == "small_mesh":
+        fx = load_case("monkey_mesh_128")
+        verts, idx, nm, queue = fx["vertices"], fx["indices"], int(fx["normal_mode"]), 16
+        eyes = ((0.0, 0.0, 0.0), (0.1, 0.05, -0.2))
+    else:
+        rng = np.random.default_rng(5)
+        nt = 20000
+        centre = rng.normal(size=(nt, 1, 3))
+        centre *= rng.uniform(1.0, 2.0, (nt, 1, 1)) / np.linalg.norm(centre, axis=2, keepdims=True)
+        tri = (centre + rng.uniform(-0.04, 0.04, (nt, 3, 3))).astype(np.float32)
+        verts = np.concatenate([tri.reshape(-1, 3), np.zeros((nt * 3, 3), np.float32)], axis=1).astype(np.float32)
+        idx = np.arange(nt * 3, dtype=np.uint32).reshape(-1, 3)
+        nm, queue = 1, 2000
+        eyes = ((0.0, 0.0, 0.0), (0.02, -0.01, 0.03))
+    sph, _ = po.reference_spheres_and_materials()
+    old = os.environ.get("PT_GRID_QUEUE")
+    os.environ["PT_GRID_QUEUE"] = str(queue)
+    try:
+        t = Tracer(0)
+    finally:
+        if old is None:
+            del os.environ["PT_GRID_QUEUE"]
+        else:
+            os.environ["PT_GRID_QUEUE"] = old
+    try:
+        prog = t.program_create(capi.PROGRAM_MESH)
+        t.use_program(prog)
+        t.upload_spheres(sph)
+        t.upload_mesh(verts, idx)
+        t.set_normal_mode(nm)
+        t.target_create(W, H)
+        t.build_accel()
+        nt = len(idx)
+        entries = []
+        for eye in eyes:
+            cam = po.camera(60.0, W, H, eye, (eye[0], eye[1], eye[2] + 1.0), (0, 1, 0))
+            t.set_uniforms(cam, nt, 10)
+            out = {}
+            for name, mode in (("auto", capi.ACCEL_AUTO), ("brute", capi.ACCEL_BRUTE)):
+                t.set_accel_mode(mode)
+                t.target_clear()
+                ids, ts = t.readback_primary()
+                t.dispatch(1, 3, 1)
+                t.finish()
+                out[name] = (ids, ts, t.readback())
+                if name == "auto":
+                    entries.append(t.stats()["grid_entries"])
+            assert np.array_equal(out["auto"][0], out["brute"][0])
+            assert n_bit_mismatch(out["auto"][1], out["brute"][1]) == 0
+            assert n_bit_mismatch(out["auto"][2], out["brute"][2]) == 0
+            assert (out["brute"][0] >= 0).mean() > 0.05
+        if scene_kind == "small_mesh":
+            assert entries == [0, 0]           # no grid: nothing fits a queue of 16
+        else:
+            assert all(e > nt for e in entries)  # a grid was built (on a coarser resolution than the preferred one)
+    finally:
+        t.close()
