@@ -93,6 +93,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        # the CPU baseline, the 1M-triangle run and the no-reuse comparison are reported by the single-GPU run only
+        # (they happen after the timed region on rank 0 and would keep the other ranks waiting at the final barrier)
+        args.no_cpu_baseline = args.no_second_scene = args.lean = True
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
