@@ -93,7 +93,7 @@ struct PtContext {
     int32_t grid_queue_override = 0;  // PT_GRID_QUEUE=n (testing): capacity of the grid build's queue of large jobs
     bool grid_res_reduced = false;  // the preferred resolution gave lists too long for this mesh
     uint64_t grid_entries = 0;
-    unsigned long long* d_grid_estimate = nullptr;   // scratch of the grid's count pass and its three-word summary
+    unsigned long long* d_grid_count_scratch = nullptr;   // scratch of the grid's count pass and its three-word summary
     unsigned long long* h_grid_summary = nullptr;    // pinned host copy of the summary
 
     // target
@@ -253,7 +253,7 @@ PtStatus build_grid(PtContext* ctx) {
     ctx->grid_built = false;
     // Resolution: the preferred one, halved while the lists could exceed 2^30 entries (4 GiB) -- many triangles that each
     // cover a large part of a fine grid. Below 32 cells per face edge the grid is given up; the other search modes remain.
-    if (!ctx->d_grid_estimate) PT_HIP_TRY(hipMalloc(&ctx->d_grid_estimate, (2 * PT_GRID_BOUND_SLOTS + 4) * sizeof(unsigned long long)));
+    if (!ctx->d_grid_count_scratch) PT_HIP_TRY(hipMalloc(&ctx->d_grid_count_scratch, (2 * PT_GRID_BOUND_SLOTS + 4) * sizeof(unsigned long long)));
     if (!ctx->h_grid_summary) PT_HIP_TRY(hipHostMalloc(&ctx->h_grid_summary, 4 * sizeof(unsigned long long)));  // pinned: one short copy per build
     PtGridBuild& g = ctx->grid;
     uint32_t total = 0, entries = 0;  // list words needed (cells with two or more triangles); all (cell, triangle) entries
@@ -276,8 +276,8 @@ PtStatus build_grid(PtContext* ctx) {
             PT_HIP_TRY(hipMalloc(&g.big_count, sizeof(uint32_t)));
         }
         // the count pass also sums the bound and stops short of the large jobs when it is exceeded
-        unsigned long long* summary = ctx->d_grid_estimate + 2 * PT_GRID_BOUND_SLOTS;
-        PT_HIP_TRY(pt_grid_count(g, ctx->d_tris, ctx->num_triangles, ctx->d_grid_estimate, summary, ctx->stream));
+        unsigned long long* summary = ctx->d_grid_count_scratch + 2 * PT_GRID_BOUND_SLOTS;
+        PT_HIP_TRY(pt_grid_count(g, ctx->d_tris, ctx->num_triangles, ctx->d_grid_count_scratch, summary, ctx->stream));
         PT_HIP_TRY(hipMemcpyAsync(ctx->h_grid_summary, summary, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
         PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
         const unsigned long long bound = ctx->h_grid_summary[0];
@@ -563,7 +563,7 @@ PtStatus pt_destroy(PtContext* ctx) {
     if (ctx->d_spheres) (void)hipFree(ctx->d_spheres);
     if (ctx->d_sphere_recs) (void)hipFree(ctx->d_sphere_recs);
     if (ctx->d_materials) (void)hipFree(ctx->d_materials);
-    if (ctx->d_grid_estimate) (void)hipFree(ctx->d_grid_estimate);
+    if (ctx->d_grid_count_scratch) (void)hipFree(ctx->d_grid_count_scratch);
     if (ctx->h_grid_summary) (void)hipHostFree(ctx->h_grid_summary);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
