@@ -305,11 +305,11 @@ def main():
                                        "latency-bound pointer chasing served by L2/Infinity Cache, far below the HBM roof"}
         if large:
             out["large_scene"] = large
-        # HBM bytes per launch from rocprofv3 PMC passes of this same workload (profiles/r01_pmc_cornell_grid_v5.json:
-        # FETCH_SIZE 20765 KB doubled as the gfx950 correction prescribes, plus WRITE_SIZE 156372.75 KB, of which 33 MB are
+        # HBM bytes per launch from rocprofv3 PMC passes of this same workload (profiles/r01_pmc_cornell_grid_v6.json:
+        # FETCH_SIZE 20762 KB doubled as the gfx950 correction prescribes, plus WRITE_SIZE 158514 KB, of which 33 MB are
         # the image and the rest the parked samples of split tiles); counters cannot be read from inside this run
         if args.workload == "cornell" and (W, H, spp) == (1920, 1080, 256):
-            out["roofline"]["traffic"] = 2 * 20765.0 * 1024 + 156372.75 * 1024
+            out["roofline"]["traffic"] = 2 * 20762.0 * 1024 + 158514.03 * 1024
             out["roofline"]["valu_issue_busy"] = 0.74
             out["roofline"]["hbm_GB_per_s"] = out["roofline"]["traffic"] / (kernel_ms * 1e-3) * 1e-9   # against the 8000 GB/s peak: the path is not HBM-bound
             out["roofline"]["hbm_frac"] = out["roofline"]["hbm_GB_per_s"] / 8000.0
