@@ -319,13 +319,30 @@ __global__ __launch_bounds__(PT_GRID_BOUND_SLOTS) void grid_summary(const unsign
     }
 }
 
+// Start of a pass, in one launch instead of three fills: the cell counters (fill cursors) to zero, the queue length to
+// zero; count pass: the bound slots to zero; fill pass: every cell word to PT_GRID_EMPTY. words = 6*res*res + 1.
+template <bool COUNT>
+__global__ __launch_bounds__(256) void grid_reset(uint32_t* __restrict__ cell_count, uint32_t* __restrict__ cells, size_t words,
+                                                  uint32_t* __restrict__ big_count, unsigned long long* __restrict__ bound) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t quads = words / 4;
+    if (i < quads) {
+        reinterpret_cast<uint4*>(cell_count)[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (!COUNT) reinterpret_cast<uint4*>(cells)[i] = make_uint4(PT_GRID_EMPTY, PT_GRID_EMPTY, PT_GRID_EMPTY, PT_GRID_EMPTY);
+    }
+    if (i < words - quads * 4) {
+        cell_count[quads * 4 + i] = 0u;
+        if (!COUNT) cells[quads * 4 + i] = PT_GRID_EMPTY;
+    }
+    if (i == 0) *big_count = 0u;
+    if (COUNT && i < 2 * PT_GRID_BOUND_SLOTS) bound[i] = 0ull;
+}
+
 template <bool COUNT>
 hipError_t bin_all(const PtGridBuild& g, const float* tris, int32_t n, unsigned long long* bound, hipStream_t stream) {
-    const size_t cells = (size_t)6 * g.res * g.res;
-    hipError_t e = hipMemsetAsync(g.cell_count, 0, (cells + 1) * sizeof(uint32_t), stream);
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(g.big_count, 0, sizeof(uint32_t), stream);
-    if (e != hipSuccess) return e;
+    const size_t words = (size_t)6 * g.res * g.res + 1;
+    const size_t threads = std::max<size_t>(words / 4, 2 * PT_GRID_BOUND_SLOTS);  // (6 * 32 * 32 / 4 = 1536 at the coarsest grid)
+    hipLaunchKernelGGL(grid_reset<COUNT>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, g.cell_count, g.cells, words, g.big_count, bound);
     const float4* t4 = reinterpret_cast<const float4*>(tris);
     hipLaunchKernelGGL(grid_bin_triangles<COUNT>, dim3((n + 127) / 128), dim3(128), 0, stream, t4, n, g.res, g.cell_count, g.cell_start, g.list,
                        g.cells, g.big_jobs, g.big_count, g.big_capacity, bound);
@@ -345,9 +362,7 @@ size_t pt_grid_scan_temp_bytes(size_t cells) {
 
 hipError_t pt_grid_count(const PtGridBuild& g, const float* tris, int32_t n, unsigned long long* slots, unsigned long long* summary, hipStream_t stream) {
     const size_t cells = (size_t)6 * g.res * g.res;
-    hipError_t e = hipMemsetAsync(slots, 0, 2 * PT_GRID_BOUND_SLOTS * sizeof(unsigned long long), stream);
-    if (e != hipSuccess) return e;
-    e = bin_all<true>(g, tris, n, slots, stream);
+    hipError_t e = bin_all<true>(g, tris, n, slots, stream);
     if (e != hipSuccess) return e;
     // list space of every cell (none for cells with fewer than two triangles)
     size_t bytes = g.scan_tmp_bytes;
@@ -359,8 +374,5 @@ hipError_t pt_grid_count(const PtGridBuild& g, const float* tris, int32_t n, uns
 }
 
 hipError_t pt_grid_fill(const PtGridBuild& g, const float* tris, int32_t n, hipStream_t stream) {
-    const size_t cells = (size_t)6 * g.res * g.res;
-    hipError_t e = hipMemsetAsync(g.cells, 0xff, (cells + 1) * sizeof(uint32_t), stream);  // PT_GRID_EMPTY
-    if (e != hipSuccess) return e;
     return bin_all<false>(g, tris, n, nullptr, stream);
 }
