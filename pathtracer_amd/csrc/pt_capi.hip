@@ -232,7 +232,7 @@ void free_bvh(PtContext* ctx) {
 
 void free_grid(PtContext* ctx) {
     PtGridBuild& g = ctx->grid;
-    void* ptrs[] = {g.cell_count, g.cell_start, g.cells, g.list, g.scan_tmp, g.big_jobs, g.big_count};
+    void* ptrs[] = {g.cell_count, g.cell_start, g.cells, g.list, g.scan_tmp, g.big_jobs, g.big_cells, g.big_count};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     g = PtGridBuild{};
@@ -273,6 +273,7 @@ PtStatus build_grid(PtContext* ctx) {
             g.big_capacity = (uint32_t)std::min<size_t>((size_t)ctx->num_triangles * 6, (size_t)4 << 20);
             if (ctx->grid_queue_override > 0) g.big_capacity = (uint32_t)ctx->grid_queue_override;
             PT_HIP_TRY(hipMalloc(&g.big_jobs, (size_t)g.big_capacity * sizeof(uint32_t)));
+            PT_HIP_TRY(hipMalloc(&g.big_cells, (size_t)g.big_capacity * sizeof(uint32_t)));
             PT_HIP_TRY(hipMalloc(&g.big_count, sizeof(uint32_t)));
         }
         // the count pass also sums the bound and stops short of the large jobs when it is exceeded

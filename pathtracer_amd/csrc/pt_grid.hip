@@ -211,8 +211,8 @@ constexpr unsigned long long kMaxListBound = 1ull << 30;
 template <bool COUNT>
 __global__ __launch_bounds__(128) void grid_bin_triangles(const float4* __restrict__ tris, int n, int res, uint32_t* __restrict__ cell_count,
                                                           const uint32_t* __restrict__ cell_start, uint32_t* __restrict__ list,
-                                                          uint32_t* __restrict__ cells_out, uint32_t* __restrict__ big_jobs, uint32_t* __restrict__ big_count, uint32_t big_capacity,
-                                                          unsigned long long* __restrict__ bound) {
+                                                          uint32_t* __restrict__ cells_out, uint32_t* __restrict__ big_jobs, uint32_t* __restrict__ big_cells,
+                                                          uint32_t* __restrict__ big_count, uint32_t big_capacity, unsigned long long* __restrict__ bound) {
     // One thread per triangle, its six faces in turn: neighbouring triangles mostly fall on the same face, so the clipping
     // (the expensive part) runs with most lanes of the wave instead of one lane in six.
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -230,6 +230,7 @@ __global__ __launch_bounds__(128) void grid_bin_triangles(const float4* __restri
             const uint32_t slot = atomicAdd(big_count, 1u);
             if (slot < big_capacity) {
                 big_jobs[slot] = (uint32_t)(i * 6 + f);
+                big_cells[slot] = (uint32_t)cells;
                 continue;
             }
             if (COUNT) {
@@ -261,8 +262,8 @@ __global__ __launch_bounds__(128) void grid_bin_triangles(const float4* __restri
 template <bool COUNT>
 __global__ __launch_bounds__(256) void grid_bin_big(const float4* __restrict__ tris, int res, uint32_t* __restrict__ cell_count,
                                                     const uint32_t* __restrict__ cell_start, uint32_t* __restrict__ list,
-                                                    uint32_t* __restrict__ cells_out, const uint32_t* __restrict__ big_jobs, const uint32_t* __restrict__ big_count, uint32_t big_capacity,
-                                                    unsigned long long* __restrict__ bound) {
+                                                    uint32_t* __restrict__ cells_out, const uint32_t* __restrict__ big_jobs, const uint32_t* __restrict__ big_cells,
+                                                    const uint32_t* __restrict__ big_count, uint32_t big_capacity, unsigned long long* __restrict__ bound) {
     if (COUNT) {  // (the bound is complete: grid_bin_triangles ran before this kernel)
         static_assert(PT_GRID_BOUND_SLOTS == 256, "one slot per thread of this block");
         __shared__ unsigned long long partial[4];
@@ -279,6 +280,8 @@ __global__ __launch_bounds__(256) void grid_bin_big(const float4* __restrict__ t
     const uint32_t parts = queued < gridDim.x ? gridDim.x / queued : 1u;
     const uint32_t part = blockIdx.x / queued;
     if (parts > 1u && part >= parts) return;
+    // (a part beyond the job's cells has nothing to do: leave before the clipping)
+    if (parts > 1u && part * blockDim.x >= big_cells[blockIdx.x % queued]) return;
     unsigned long long my_entries = 0;
     for (uint32_t slot = parts > 1u ? blockIdx.x % queued : blockIdx.x; slot < queued; slot += gridDim.x) {
         const int j = (int)big_jobs[slot], i = j / 6, f = j % 6;
@@ -345,9 +348,9 @@ hipError_t bin_all(const PtGridBuild& g, const float* tris, int32_t n, unsigned 
     hipLaunchKernelGGL(grid_reset<COUNT>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, g.cell_count, g.cells, words, g.big_count, bound);
     const float4* t4 = reinterpret_cast<const float4*>(tris);
     hipLaunchKernelGGL(grid_bin_triangles<COUNT>, dim3((n + 127) / 128), dim3(128), 0, stream, t4, n, g.res, g.cell_count, g.cell_start, g.list,
-                       g.cells, g.big_jobs, g.big_count, g.big_capacity, bound);
+                       g.cells, g.big_jobs, g.big_cells, g.big_count, g.big_capacity, bound);
     hipLaunchKernelGGL(grid_bin_big<COUNT>, dim3(2048), dim3(256), 0, stream, t4, g.res, g.cell_count, g.cell_start, g.list, g.cells, g.big_jobs,
-                       g.big_count, g.big_capacity, bound);
+                       g.big_cells, g.big_count, g.big_capacity, bound);
     return hipGetLastError();
 }
 

@@ -84,6 +84,7 @@ struct PtGridBuild {
     void* scan_tmp;
     size_t scan_tmp_bytes;
     uint32_t* big_jobs;     // queue of (triangle, face) jobs that cover many cells: one workgroup each
+    uint32_t* big_cells;    // ... and how many cells each covers (its bounding box)
     uint32_t* big_count;    // 1
     uint32_t big_capacity;
 };
