@@ -145,6 +145,7 @@ struct PtContext {
         uint32_t program;
     } primary_cache_key{};
     int sched_mode = 2;             // 0 raster order, 1 cost-ordered tiles, 2 cost-ordered items with heavy tiles split by samples
+    int32_t fail_grid_alloc = 0, grid_allocs = 0;  // PT_FAIL_GRID_ALLOC=k (testing): the k-th allocation of the grid build fails
 
     // uniforms
     PtUniforms uniforms{};
@@ -239,6 +240,14 @@ void free_grid(PtContext* ctx) {
     ctx->grid_built = false;
 }
 
+// hipMalloc for the grid's arrays. PT_FAIL_GRID_ALLOC=k (testing) makes the k-th of these calls in the context's life
+// report out-of-memory, to exercise the clean-up paths.
+template <typename T>
+hipError_t grid_alloc(PtContext* ctx, T** ptr, size_t bytes) {
+    if (ctx->fail_grid_alloc > 0 && ++ctx->grid_allocs == ctx->fail_grid_alloc) return hipErrorOutOfMemory;
+    return hipMalloc(reinterpret_cast<void**>(ptr), bytes);
+}
+
 // Cube-map resolution per face: about sixteen cells per triangle over the sphere, within [512, 2048]
 int grid_resolution(const PtContext* ctx) {
     if (ctx->grid_res_override > 0) return ctx->grid_res_override;
@@ -253,8 +262,10 @@ PtStatus build_grid(PtContext* ctx) {
     ctx->grid_built = false;
     // Resolution: the preferred one, halved while the lists could exceed 2^30 entries (4 GiB) -- many triangles that each
     // cover a large part of a fine grid. Below 32 cells per face edge the grid is given up; the other search modes remain.
-    if (!ctx->d_grid_count_scratch) PT_HIP_TRY(hipMalloc(&ctx->d_grid_count_scratch, (2 * PT_GRID_BOUND_SLOTS + 4) * sizeof(unsigned long long)));
-    if (!ctx->h_grid_summary) PT_HIP_TRY(hipHostMalloc(&ctx->h_grid_summary, 4 * sizeof(unsigned long long)));  // pinned: one short copy per build
+    if (!ctx->d_grid_count_scratch || !ctx->h_grid_summary) {
+        if (!ctx->d_grid_count_scratch) PT_HIP_TRY(hipMalloc(&ctx->d_grid_count_scratch, (2 * PT_GRID_BOUND_SLOTS + 4) * sizeof(unsigned long long)));
+        if (!ctx->h_grid_summary) PT_HIP_TRY(hipHostMalloc(&ctx->h_grid_summary, 4 * sizeof(unsigned long long)));  // pinned: one short copy per build
+    }
     PtGridBuild& g = ctx->grid;
     uint32_t total = 0, entries = 0;  // list words needed (cells with two or more triangles); all (cell, triangle) entries
     size_t cells = 0;
@@ -266,15 +277,20 @@ PtStatus build_grid(PtContext* ctx) {
             free_grid(ctx);
             g.res = res;
             g.scan_tmp_bytes = pt_grid_scan_temp_bytes(cells);
-            PT_HIP_TRY(hipMalloc(&g.cell_count, (cells + 1) * sizeof(uint32_t)));
-            PT_HIP_TRY(hipMalloc(&g.cell_start, (cells + 1) * sizeof(uint32_t)));
-            PT_HIP_TRY(hipMalloc(&g.cells, (cells + 1) * sizeof(uint32_t)));
-            PT_HIP_TRY(hipMalloc(&g.scan_tmp, g.scan_tmp_bytes ? g.scan_tmp_bytes : 16));
             g.big_capacity = (uint32_t)std::min<size_t>((size_t)ctx->num_triangles * 6, (size_t)4 << 20);
             if (ctx->grid_queue_override > 0) g.big_capacity = (uint32_t)ctx->grid_queue_override;
-            PT_HIP_TRY(hipMalloc(&g.big_jobs, (size_t)g.big_capacity * sizeof(uint32_t)));
-            PT_HIP_TRY(hipMalloc(&g.big_cells, (size_t)g.big_capacity * sizeof(uint32_t)));
-            PT_HIP_TRY(hipMalloc(&g.big_count, sizeof(uint32_t)));
+            hipError_t e = grid_alloc(ctx, &g.cell_count, (cells + 1) * sizeof(uint32_t));
+            if (e == hipSuccess) e = grid_alloc(ctx, &g.cell_start, (cells + 1) * sizeof(uint32_t));
+            if (e == hipSuccess) e = grid_alloc(ctx, &g.cells, (cells + 1) * sizeof(uint32_t));
+            if (e == hipSuccess) e = grid_alloc(ctx, &g.scan_tmp, g.scan_tmp_bytes ? g.scan_tmp_bytes : 16);
+            if (e == hipSuccess) e = grid_alloc(ctx, &g.big_jobs, (size_t)g.big_capacity * sizeof(uint32_t));
+            if (e == hipSuccess) e = grid_alloc(ctx, &g.big_cells, (size_t)g.big_capacity * sizeof(uint32_t));
+            if (e == hipSuccess) e = grid_alloc(ctx, &g.big_count, sizeof(uint32_t));
+            if (e != hipSuccess) {
+                // no half-made grid: res goes back to 0, so the next build starts with the allocations again
+                free_grid(ctx);
+                return fail(PT_ERR_HIP, "direction grid: allocation failed at %d cells per face edge: %s", res, hipGetErrorString(e));
+            }
         }
         // the count pass also sums the bound and stops short of the large jobs when it is exceeded
         unsigned long long* summary = ctx->d_grid_count_scratch + 2 * PT_GRID_BOUND_SLOTS;
@@ -291,7 +307,8 @@ PtStatus build_grid(PtContext* ctx) {
         g.list = nullptr;
         g.list_capacity = 0;
         const size_t cap = (size_t)total + (size_t)total / 8 + 64;
-        PT_HIP_TRY(hipMalloc(&g.list, cap * sizeof(uint32_t)));
+        hipError_t e = grid_alloc(ctx, &g.list, cap * sizeof(uint32_t));
+        if (e != hipSuccess) return fail(PT_ERR_HIP, "direction grid: allocating %zu list entries failed: %s", cap, hipGetErrorString(e));
         g.list_capacity = cap;
     }
     PT_HIP_TRY(pt_grid_fill(g, ctx->d_tris, ctx->num_triangles, ctx->stream));
@@ -546,6 +563,7 @@ PtStatus pt_create(int32_t device, PtContext** out_ctx) {
     if (const char* g = getenv("PT_AUTO_GRID")) ctx->auto_grid = g[0] != '0';
     if (const char* g = getenv("PT_PRIMARY_CACHE")) ctx->primary_cache_enabled = g[0] != '0';
     if (const char* g = getenv("PT_GRID_QUEUE")) ctx->grid_queue_override = atoi(g);
+    if (const char* g = getenv("PT_FAIL_GRID_ALLOC")) ctx->fail_grid_alloc = atoi(g);
     if (const char* g = getenv("PT_GRID_RES")) ctx->grid_res_override = std::min(atoi(g), 8192);  // cell indices stay far below 2^32
     if (const char* l = getenv("PT_LANE_WALK")) ctx->lane_walk = l[0] != '0';
     if (const char* l = getenv("PT_LANE_STACK_LIMIT")) ctx->lane_stack_limit = std::max(0, std::min(PT_LANE_STACK, atoi(l)));
@@ -589,9 +607,14 @@ PtStatus pt_program_create(PtContext* ctx, PtProgramKind kind, uint32_t* out_pro
     *out_program = 0;
     PT_REQUIRE(kind == PT_PROGRAM_WORLD || kind == PT_PROGRAM_MESH, PT_ERR_INVALID_ARGUMENT, "unknown program kind %d", (int)kind);
     Program p;
-    p.handle = ctx->next_program++;
+    p.handle = ctx->next_program;
     p.kind = kind;
-    ctx->programs.push_back(p);
+    try {
+        ctx->programs.push_back(p);
+    } catch (...) {
+        return fail(PT_ERR_HIP, "out of host memory");
+    }
+    ++ctx->next_program;
     *out_program = p.handle;
     return PT_OK;
 }
@@ -808,9 +831,13 @@ PtStatus pt_target_create(PtContext* ctx, int32_t width, int32_t height) {
     PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
     free_target(ctx);
     const size_t bytes = (size_t)width * height * 4 * sizeof(float);
-    PT_HIP_TRY(hipMalloc(&ctx->d_image[0], bytes));
     ctx->image_owned = true;
-    PT_HIP_TRY(hipMalloc(&ctx->d_image[1], bytes));
+    hipError_t e = hipMalloc(&ctx->d_image[0], bytes);
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_image[1], bytes);
+    if (e != hipSuccess) {
+        free_target(ctx);  // no half-made target: later calls report "no accumulation target"
+        return fail(PT_ERR_HIP, "allocating two %dx%d RGBA32F images failed: %s", width, height, hipGetErrorString(e));
+    }
     s = target_common(ctx, width, height);
     if (s != PT_OK) {
         free_target(ctx);  // no half-made target: later calls report "no accumulation target"
@@ -890,11 +917,10 @@ PtStatus pt_set_uniforms(PtContext* ctx, const PtUniforms* uniforms) {
 
 }  // extern "C"
 namespace {
-// One render launch (plus the fold of split tiles) over a range of samples.
-PtStatus dispatch_range(PtContext* ctx, int32_t first_sample, int32_t num_samples, int32_t stride) {
-    PtKernelParams p;
-    const Program* prog = nullptr;
-    PtStatus s = fill_params(ctx, &p, &prog);
+// First half of a render launch over a range of samples: kernel parameters, source and destination image.
+PtStatus begin_pass(PtContext* ctx, PtKernelParams* pp, const Program** prog_out, int32_t first_sample, int32_t num_samples, int32_t stride) {
+    PtKernelParams& p = *pp;
+    PtStatus s = fill_params(ctx, &p, prog_out);
     if (s != PT_OK) return s;
     p.first_sample = first_sample;
     p.num_samples = num_samples;
@@ -907,6 +933,17 @@ PtStatus dispatch_range(PtContext* ctx, int32_t first_sample, int32_t num_sample
     if (partial && p.dst != p.src) {
         PT_HIP_TRY(hipMemcpyAsync(p.dst, p.src, (size_t)ctx->width * ctx->height * 16, hipMemcpyDeviceToDevice, ctx->stream));
     }
+    return PT_OK;
+}
+
+PtStatus end_pass(PtContext* ctx, PtKernelParams& p, const Program* prog, int32_t num_samples);
+
+// One render launch (plus the fold of split tiles) over a range of samples.
+PtStatus dispatch_range(PtContext* ctx, int32_t first_sample, int32_t num_samples, int32_t stride) {
+    PtKernelParams p;
+    const Program* prog = nullptr;
+    PtStatus s = begin_pass(ctx, &p, &prog, first_sample, num_samples, stride);
+    if (s != PT_OK) return s;
     // Tile order: the costs measured by the previous dispatch of this same window put the expensive tiles first.
     // It is only a scheduling hint (any order renders the same image), so stale costs after a camera or scene change
     // are harmless.
@@ -965,6 +1002,7 @@ PtStatus dispatch_range(PtContext* ctx, int32_t first_sample, int32_t num_sample
                     break;
                 }
                 PT_HIP_TRY(hipMemsetAsync(ctx->d_tile_cost, 0, (size_t)tiles * sizeof(uint32_t), ctx->stream));
+                ctx->costs_stale = false;  // from here on the costs are those of the current mesh and camera position
                 // split tiles park their samples in scratch memory: 8 (materials mode 16) bytes per pixel and sample
                 const size_t need = (size_t)c[1] * slot_bytes;
                 if (need > ctx->sample_scratch_bytes) {
@@ -1005,6 +1043,11 @@ PtStatus dispatch_range(PtContext* ctx, int32_t first_sample, int32_t num_sample
         memcpy(ctx->sched_win, ctx->win, sizeof ctx->win);
         ctx->sched_have_cost = true;
     }
+    return end_pass(ctx, p, prog, num_samples);
+}
+
+// Second half: the camera-ray hits kept between dispatches, the launch, the image swap, the sample count.
+PtStatus end_pass(PtContext* ctx, PtKernelParams& p, const Program* prog, int32_t num_samples) {
     // Camera-ray hits of this view: read if an earlier dispatch left them, written otherwise (reference shading only; the
     // materials mode also needs the distance).
     const bool cache_usable = ctx->primary_cache_enabled && ctx->primary_reuse && p.depth > 0 &&
@@ -1129,7 +1172,7 @@ PtStatus pt_readback_primary(PtContext* ctx, int32_t* ids, float* t) {
     const size_t n = (size_t)ctx->width * ctx->height;
     // pixels outside the window report a miss
     PT_HIP_TRY(hipMemsetAsync(ctx->d_ids, 0xff, n * sizeof(int32_t), ctx->stream));
-    PT_HIP_TRY(hipMemsetAsync(ctx->d_t, 0, n * sizeof(float), ctx->stream));
+    PT_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ctx->d_t), 0x7e967699 /* 1e38f */, n, ctx->stream));
     PT_HIP_TRY(pt_launch_primary(p, (int)prog->kind, ctx->stream));
     if (ids) PT_HIP_TRY(hipMemcpyAsync(ids, ctx->d_ids, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     if (t) PT_HIP_TRY(hipMemcpyAsync(t, ctx->d_t, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
@@ -1153,12 +1196,16 @@ PtStatus pt_get_stats(PtContext* ctx, PtStats* out) {
     PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
     s = collect_timing(ctx);
     if (s != PT_OK) return s;
-    std::vector<unsigned long long> slots((size_t)PT_COUNTER_SLOTS * PT_COUNTER_STRIDE);
-    PT_HIP_TRY(hipMemcpyAsync(slots.data(), ctx->d_counters, kCounterBytes, hipMemcpyDeviceToHost, ctx->stream));
-    PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    unsigned long long* slots = new (std::nothrow) unsigned long long[(size_t)PT_COUNTER_SLOTS * PT_COUNTER_STRIDE];
+    PT_REQUIRE(slots != nullptr, PT_ERR_HIP, "out of host memory");
+    hipError_t ce = hipMemcpyAsync(slots, ctx->d_counters, kCounterBytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (ce == hipSuccess) ce = hipStreamSynchronize(ctx->stream);
     unsigned long long c[6] = {0, 0, 0, 0, 0, 0};
-    for (size_t k = 0; k < PT_COUNTER_SLOTS; ++k)
-        for (int j = 0; j < 6; ++j) c[j] += slots[k * PT_COUNTER_STRIDE + j];
+    if (ce == hipSuccess)
+        for (size_t k = 0; k < PT_COUNTER_SLOTS; ++k)
+            for (int j = 0; j < 6; ++j) c[j] += slots[k * PT_COUNTER_STRIDE + j];
+    delete[] slots;
+    PT_HIP_TRY(ce);
     out->rays = c[0];
     out->rays_traced = c[4];
     out->samples = ctx->samples;

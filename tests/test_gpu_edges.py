@@ -320,3 +320,63 @@ def test_camera_ray_hits_kept_between_dispatches(kind):
     finally:
         for t in tracers:
             t.close()
+
+
+@pytest.mark.parametrize("kth", [1, 3, 7, 8])
+def test_failed_grid_allocation_leaves_no_half_made_grid(kth):
+    """The k-th device allocation of the direction-grid build reports out-of-memory (PT_FAIL_GRID_ALLOC, a test knob read
+    at pt_create): the dispatch returns PT_ERR_HIP, and the next one builds the grid from scratch and renders the oracle's
+    image -- no launch on null arrays."""
+    import os
+    from pathtracer_amd import PtError, Tracer
+    fx = load_case("monkey_mesh_128")
+    os.environ["PT_FAIL_GRID_ALLOC"] = str(kth)
+    try:
+        t = Tracer(0)
+    finally:
+        del os.environ["PT_FAIL_GRID_ALLOC"]
+    try:
+        prog, scene, u = upload(t, fx, 64, 48)
+        t.build_accel()
+        t.set_accel_mode(4)
+        with pytest.raises(PtError) as err:
+            t.dispatch(1, 3, 1)
+        assert err.value.status == 2 and "grid" in str(err.value)
+        t.dispatch(1, 3, 1)
+        t.finish()
+        ref, _ = po.render(scene, u, 1, 3)
+        assert n_bit_mismatch(t.readback(), ref) == 0
+        assert t.stats()["grid_entries"] > 0
+        t.program_destroy(prog)
+    finally:
+        t.close()
+
+
+def test_tile_costs_are_fresh_after_a_move_and_short_dispatches(tracer, capfd):
+    """After a camera move, single-sample frames gather costs for the new view; the long dispatch that follows is scheduled
+    from them in one go (one scheduler run over all its samples) instead of being treated as a view without costs, which
+    would render an 8-sample probe first."""
+    import os
+    fx = load_case("monkey_mesh_128")
+    prog, scene, u = upload(tracer, fx, 128, 128)
+    ntri = len(fx["indices"])
+    for k in range(3):
+        tracer.dispatch(1 + k, 1, 1)
+    tracer.set_uniforms(po.camera(60.0, 128, 128, (0.1, 0.0, 0.05), (0, 0, 1), (0, 1, 0)), ntri, 10)   # the move
+    tracer.target_clear()
+    for k in range(3):
+        tracer.dispatch(1 + k, 1, 1)
+    tracer.finish()
+    capfd.readouterr()
+    os.environ["PT_DEBUG_SCHED"] = "1"
+    try:
+        tracer.dispatch(4, 64, 1)
+        tracer.finish()
+    finally:
+        del os.environ["PT_DEBUG_SCHED"]
+    lines = [l for l in capfd.readouterr().err.splitlines() if l.startswith("[pt sched]")]
+    assert lines and all(" 64 samples" in l for l in lines), lines
+    u2 = po.uniforms(po.camera(60.0, 128, 128, (0.1, 0.0, 0.05), (0, 0, 1), (0, 1, 0)), 128, 128, ntri, 10, 1, int(fx["normal_mode"]))
+    ref, _ = po.render(scene, u2, 1, 67, threads=8)
+    assert n_bit_mismatch(tracer.readback(), ref) == 0
+    tracer.program_destroy(prog)
