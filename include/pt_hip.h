@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 4
+#define PT_ABI_VERSION 5
 
 typedef enum PtStatus {
     PT_OK = 0,
@@ -220,6 +220,20 @@ PtStatus pt_set_uniforms(PtContext* ctx, const PtUniforms* uniforms);
  * kept (16 bytes per pixel) until uniforms, window, row partition, modes, program or mesh change, so single-sample
  * dispatches of a standing camera do not evaluate it again; the images are the same either way. */
 PtStatus pt_dispatch(PtContext* ctx, int32_t first_sample, int32_t num_samples, int32_t stride);
+/* pt_dispatch for callers that cannot allocate. No counterpart in the reference: it is for hosts that may not call
+ * hipMalloc where they render -- tight serving loops, code that forbids allocation, harnesses that check for it. Same
+ * arguments, same image bit for bit, but the call allocates nothing (no hipMalloc, hipFree or allocating library routine):
+ * per-tile costs, the work list and the parked samples of split tiles live in a fixed 64 MiB array that is part of the
+ * library's device image (one copy per GPU, held until the process ends) instead of the context's grown-on-demand buffers,
+ * and the scheduler's counts are not read back -- launches are sized for the largest list the array holds.
+ * Limits: a window of at most 131,072 tiles of 8x8 pixels (3840x2160 fits; larger windows: PT_ERR_UNSUPPORTED); the parked
+ * samples get 63 MiB, so a range of n samples can split at most 63 MiB / (n x 512 B) tiles (1 KiB in PT_SHADE_MATERIALS),
+ * fewer than pt_dispatch would: slower on views whose work sits in few tiles, never different. Everything the call needs
+ * must exist already: target, scene, and -- for the direction grid -- arrays large enough for the current camera position
+ * (one pt_dispatch of the view makes them; otherwise PT_ERR_STATE and nothing is rendered). It keeps no tile costs between
+ * calls: a range of 32 samples or more is two launches (8 samples, then the rest scheduled by their costs), shorter ones one.
+ * All contexts on a GPU share that GPU's array: calls that overlap on one GPU (two streams, two threads) race. */
+PtStatus pt_dispatch_static(PtContext* ctx, int32_t first_sample, int32_t num_samples, int32_t stride);
 /* Replaces glFinish (PathTracer.cpp:1403): waits for the stream and reports any kernel fault. */
 PtStatus pt_finish(PtContext* ctx);
 
@@ -235,7 +249,7 @@ PtStatus pt_present_rgba8(PtContext* ctx, uint8_t* dst);
 PtStatus pt_current_image(PtContext* ctx, void** out_device_ptr);
 /* Traces primary rays only and copies per-pixel closest-hit ids (int32; -1 = miss; sphere id for
  * PT_PROGRAM_WORLD, triangle id for PT_PROGRAM_MESH) and hit distances (1e38 on a miss). Either may be NULL. Only the
- * pixels of the window (and of this context's row blocks, pt_set_row_interleave) are filled in. */
+ * pixels of the window (and of this context's row blocks, pt_set_row_interleave) are traced; all others report a miss. */
 PtStatus pt_readback_primary(PtContext* ctx, int32_t* ids, float* t);
 PtStatus pt_enable_timing(PtContext* ctx, int32_t enabled);
 PtStatus pt_get_stats(PtContext* ctx, PtStats* out);

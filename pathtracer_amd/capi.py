@@ -67,6 +67,7 @@ SIGNATURES = {
     "pt_set_accum_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "pt_set_uniforms": (C.c_int, [C.c_void_p, C.POINTER(PtUniforms)]),
     "pt_dispatch": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "pt_dispatch_static": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "pt_finish": (C.c_int, [C.c_void_p]),
     "pt_readback_rgba32f": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pt_present_rgba8": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -218,6 +219,10 @@ class Tracer:
 
     def dispatch(self, first_sample, num_samples=1, stride=1):
         check(self._lib.pt_dispatch(self._ctx, first_sample, num_samples, stride), self._lib)
+
+    def dispatch_static(self, first_sample, num_samples=1, stride=1):
+        """pt_dispatch that allocates nothing (fixed scratch array in the library's device image)."""
+        check(self._lib.pt_dispatch_static(self._ctx, first_sample, num_samples, stride), self._lib)
 
     def finish(self):
         check(self._lib.pt_finish(self._ctx), self._lib)

@@ -9,10 +9,35 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
+// ---- scratch of pt_dispatch_static (the dispatch that allocates nothing) -------------------------------------------------
+// One array per GPU, part of the library's device image, held by every device the library runs on until the process ends.
+// Layout (byte offsets): per-tile costs | work list | scratch slot -> tile | the scheduler's two counts | the scheduler's
+// bucket counts | parked samples of split tiles. In host code the array's NAME is only a handle for hipGetSymbolAddress;
+// the device address it has on each GPU is looked up once per device in pt_create and kept in g_scratch_ptr.
+#define PT_STATIC_MAX_TILES 131072u  // 8x8-pixel tiles of the window: 3840x2160 has 129,600
+#define PT_STATIC_MAX_SPLIT 8192u    // tiles whose samples several blocks share (= the wave slots of the device)
+#define PT_STATIC_SCRATCH_BYTES ((size_t)64 << 20)
+static __device__ __align__(256) unsigned char scratch[PT_STATIC_SCRATCH_BYTES];
+
 namespace {
+
+constexpr size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+constexpr size_t kStaticCostOff = 0;
+constexpr size_t kStaticItemsOff = align256(kStaticCostOff + (size_t)PT_STATIC_MAX_TILES * sizeof(uint32_t));
+constexpr size_t kStaticSplitOff = align256(kStaticItemsOff + ((size_t)PT_STATIC_MAX_TILES + PT_STATIC_MAX_SPLIT) * sizeof(PtWorkItem));
+constexpr size_t kStaticCountsOff = align256(kStaticSplitOff + (size_t)PT_STATIC_MAX_SPLIT * sizeof(uint32_t));
+constexpr size_t kStaticTmpOff = align256(kStaticCountsOff + 2 * sizeof(uint32_t));
+constexpr size_t kStaticSamplesOff = align256(kStaticTmpOff + (size_t)PT_SCHED_TMP_WORDS * sizeof(uint32_t));
+static_assert(kStaticSamplesOff < PT_STATIC_SCRATCH_BYTES / 8, "the parked samples get most of the array");
+constexpr size_t kStaticSampleBytes = PT_STATIC_SCRATCH_BYTES - kStaticSamplesOff;
+
+constexpr int kMaxDevices = 64;
+void* g_scratch_ptr[kMaxDevices] = {};  // device address of `scratch` on each GPU (each holds its own copy)
+std::mutex g_scratch_mutex;
 
 thread_local char g_error[512] = "";
 
@@ -146,6 +171,7 @@ struct PtContext {
     } primary_cache_key{};
     int sched_mode = 2;             // 0 raster order, 1 cost-ordered tiles, 2 cost-ordered items with heavy tiles split by samples
     int32_t fail_grid_alloc = 0, grid_allocs = 0;  // PT_FAIL_GRID_ALLOC=k (testing): the k-th allocation of the grid build fails
+    bool no_alloc = false;          // inside pt_dispatch_static: whatever would allocate device or host memory fails instead
 
     // uniforms
     PtUniforms uniforms{};
@@ -263,6 +289,7 @@ PtStatus build_grid(PtContext* ctx) {
     // Resolution: the preferred one, halved while the lists could exceed 2^30 entries (4 GiB) -- many triangles that each
     // cover a large part of a fine grid. Below 32 cells per face edge the grid is given up; the other search modes remain.
     if (!ctx->d_grid_count_scratch || !ctx->h_grid_summary) {
+        PT_REQUIRE(!ctx->no_alloc, PT_ERR_STATE, "the direction grid has never been built for this context: render one frame with pt_dispatch first");
         if (!ctx->d_grid_count_scratch) PT_HIP_TRY(hipMalloc(&ctx->d_grid_count_scratch, (2 * PT_GRID_BOUND_SLOTS + 4) * sizeof(unsigned long long)));
         if (!ctx->h_grid_summary) PT_HIP_TRY(hipHostMalloc(&ctx->h_grid_summary, 4 * sizeof(unsigned long long)));  // pinned: one short copy per build
     }
@@ -274,6 +301,8 @@ PtStatus build_grid(PtContext* ctx) {
         if (res < 32) return PT_OK;
         cells = (size_t)6 * res * res;
         if (g.res != res) {
+            PT_REQUIRE(!ctx->no_alloc, PT_ERR_STATE, "the direction grid must be rebuilt at %d cells per face edge (it has %d), which allocates: "
+                       "render one frame of this view with pt_dispatch first", res, g.res);
             free_grid(ctx);
             g.res = res;
             g.scan_tmp_bytes = pt_grid_scan_temp_bytes(cells);
@@ -303,6 +332,8 @@ PtStatus build_grid(PtContext* ctx) {
         if (bound < PT_GRID_MAX_LIST_BOUND) break;
     }
     if ((size_t)total > g.list_capacity) {
+        PT_REQUIRE(!ctx->no_alloc, PT_ERR_STATE, "the direction grid of this camera position needs %u list entries and %zu are allocated: "
+                   "render one frame of this view with pt_dispatch first", total, g.list_capacity);
         if (g.list) (void)hipFree(g.list);
         g.list = nullptr;
         g.list_capacity = 0;
@@ -538,6 +569,18 @@ PtStatus pt_create(int32_t device, PtContext** out_ctx) {
     PT_HIP_TRY(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(PT_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 code only", device, prop.gcnArchName);
+    if (device < kMaxDevices) {
+        // Device address of this GPU's copy of the scratch array of pt_dispatch_static: looked up once per device, with
+        // that device current. From here on host code uses this pointer, never the array's name.
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (!g_scratch_ptr[device]) {
+            void* ptr = nullptr;
+            hipError_t se = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+            if (se != hipSuccess || ptr == nullptr)
+                return fail(PT_ERR_HIP, "hipGetSymbolAddress(scratch) failed on device %d: %s", device, hipGetErrorString(se));
+            g_scratch_ptr[device] = ptr;
+        }
+    }
     PtContext* ctx = new (std::nothrow) PtContext();
     PT_REQUIRE(ctx != nullptr, PT_ERR_HIP, "out of host memory");
     ctx->device = device;
@@ -1113,6 +1156,85 @@ PtStatus pt_dispatch(PtContext* ctx, int32_t first_sample, int32_t num_samples, 
         s = dispatch_range(ctx, first_sample, num_samples, stride);
     }
     if (s != PT_OK) return s;
+    if (ctx->timing) {
+        PT_HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
+        ctx->ev_pending = true;
+    }
+    ctx->dispatches += 1;
+    return PT_OK;
+}
+
+PtStatus pt_dispatch_static(PtContext* ctx, int32_t first_sample, int32_t num_samples, int32_t stride) {
+    PtStatus s = bind(ctx);
+    if (s != PT_OK) return s;
+    PT_REQUIRE(first_sample >= 1, PT_ERR_INVALID_ARGUMENT, "first_sample is 1-based; got %d", first_sample);
+    PT_REQUIRE(num_samples >= 1 && stride >= 1, PT_ERR_INVALID_ARGUMENT, "num_samples and stride must be >= 1");
+    PT_REQUIRE((int64_t)first_sample + (int64_t)(num_samples - 1) * stride <= (1 << 24), PT_ERR_INVALID_ARGUMENT,
+               "sample index exceeds 2^24 (u_Samples is a float)");
+    PT_REQUIRE(ctx->d_image[0] != nullptr, PT_ERR_STATE, "no accumulation target: call pt_target_create first");
+    unsigned char* base = ctx->device < kMaxDevices ? static_cast<unsigned char*>(g_scratch_ptr[ctx->device]) : nullptr;
+    PT_REQUIRE(base != nullptr, PT_ERR_STATE, "no scratch array on device %d", ctx->device);
+    const size_t tiles = (size_t)PT_TILES_ACROSS(ctx->win[2]) * PT_TILES_ACROSS(ctx->win[3]);
+    PT_REQUIRE(tiles <= PT_STATIC_MAX_TILES, PT_ERR_UNSUPPORTED,
+               "pt_dispatch_static: the %dx%d window has %zu tiles of %dx%d pixels; its fixed scratch array serves at most %u "
+               "(a 3840x2160 window). Use pt_dispatch for larger windows", ctx->win[2], ctx->win[3], tiles, PT_TILE_DIM, PT_TILE_DIM,
+               PT_STATIC_MAX_TILES);
+    uint32_t* cost = reinterpret_cast<uint32_t*>(base + kStaticCostOff);
+    PtWorkItem* items = reinterpret_cast<PtWorkItem*>(base + kStaticItemsOff);
+    uint32_t* split_tiles = reinterpret_cast<uint32_t*>(base + kStaticSplitOff);
+    uint32_t* counts = reinterpret_cast<uint32_t*>(base + kStaticCountsOff);
+    uint32_t* tmp = reinterpret_cast<uint32_t*>(base + kStaticTmpOff);
+    float* parked = reinterpret_cast<float*>(base + kStaticSamplesOff);
+
+    // Whatever a dispatch brings up to date for the mesh and the camera position (records, hierarchy boxes, direction
+    // grid) is launched here too, but nothing may allocate: a grid that needs new arrays is an error of this call.
+    struct NoAlloc {
+        PtContext* c;
+        explicit NoAlloc(PtContext* ctx) : c(ctx) { c->no_alloc = true; }
+        ~NoAlloc() { c->no_alloc = false; }
+    } guard(ctx);
+
+    PtKernelParams p;
+    const Program* prog = nullptr;
+    // Like a pt_dispatch that has no tile costs to go by, a long range renders its first samples on their own and the
+    // costs they record schedule the rest -- with the launches sized for the largest list the array can hold instead of
+    // the scheduler's counts, which are not read back. Any list that covers every (tile, sample) once renders the image
+    // pt_dispatch renders.
+    const int32_t probe = (ctx->sched_mode == 2 && num_samples >= 4 * PT_PROBE_SAMPLES) ? PT_PROBE_SAMPLES : 0;
+    s = begin_pass(ctx, &p, &prog, first_sample, probe ? probe : num_samples, stride);
+    if (s != PT_OK) return s;
+    if (ctx->timing) {
+        s = collect_timing(ctx);
+        if (s != PT_OK) return s;
+        PT_HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
+    }
+    if (probe) {
+        // the array keeps what the last call left in it: the costs start at zero
+        PT_HIP_TRY(hipMemsetAsync(cost, 0, tiles * sizeof(uint32_t), ctx->stream));
+        p.tile_cost = cost;
+    }
+    s = end_pass(ctx, p, prog, probe ? probe : num_samples);
+    if (s != PT_OK) return s;
+    if (probe) {
+        const int32_t rest = num_samples - probe;
+        const int entry_bytes = ctx->shading_mode == PT_SHADE_MATERIALS && prog->kind != PT_PROGRAM_WORLD ? 16 : 8;
+        const size_t slot_bytes = (size_t)rest * PT_TILE_THREADS * (size_t)entry_bytes;
+        s = begin_pass(ctx, &p, &prog, first_sample + probe * stride, rest, stride);
+        if (s != PT_OK) return s;
+        const float factor = ctx->split_factor >= 0.f ? std::min(ctx->split_factor, (float)PT_MAX_SPLIT_FACTOR)
+                                                      : ((p.bvh_nodes || p.bvh_nodes_abs) ? 4.0f : 1.0f);
+        size_t max_split = std::min<size_t>((size_t)(factor * (float)ctx->wave_slots), PT_STATIC_MAX_SPLIT);
+        max_split = std::min(max_split, kStaticSampleBytes / slot_bytes);  // as many split tiles as the array can park
+        PT_HIP_TRY(pt_launch_schedule_items(cost, items, counts, split_tiles, tmp, (int)tiles, rest, (int)max_split, ctx->stream));
+        p.items = items;
+        p.sched_counts = counts;
+        p.split_tiles = split_tiles;
+        p.sample_scratch = parked;
+        p.max_items = (int32_t)(tiles + max_split);   // upper bounds: blocks beyond the scheduler's counts leave at once
+        p.max_split_tiles = (int32_t)max_split;
+        s = end_pass(ctx, p, prog, rest);
+        if (s != PT_OK) return s;
+    }
     if (ctx->timing) {
         PT_HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
         ctx->ev_pending = true;
