@@ -219,7 +219,43 @@ def rng_fixture(scene):
     return out
 
 
+def config4_cases():
+    """BASELINE configuration 4: catmark_torus_creases0.obj and the torus next to its deterministically distorted copy
+    (pathtracer_amd/scenes.py builds it; the reference's data/distordedmesh/*.bin is loaded by nothing). Both fit the
+    reference's own 1024-texel scene textures (64 / 128 triangles, 32 / 64 vertices), so the unmodified upload path serves.
+    Geometric normals: the file has no vn."""
+    sys.path.insert(0, ROOT)
+    from pathtracer_amd.scenes import SceneData
+    sph, mat = po.reference_spheres_and_materials()
+    ref_cam = lambda W, H: po.camera(60.0, W, H, (0, 0, 0), (0, 0, 1), (0, 1, 0))
+    t = SceneData("torus")
+    torus = po.Scene(t.vertices, t.indices, sph, mat)
+    d = SceneData("torus_distorted")
+    both = po.Scene(d.vertices, d.indices, sph, mat)
+    geo = po.NORMALS_GEOMETRIC
+    return [("torus_geo_128", torus, ref_cam(128, 128), 128, 128, po.VARIANT_MESH, geo, [1, 2, 16], None),
+            ("torus_distorted_geo_128", both, ref_cam(128, 128), 128, 128, po.VARIANT_MESH, geo, [1, 2, 16], None),
+            ("torus_distorted_geo_256x144", both, ref_cam(256, 144), 256, 144, po.VARIANT_MESH, geo, [1, 4], None),
+            # 64x64 pixels of the 3840x2160 frame on the silhouette of the distorted copy (several triangles and sky)
+            ("torus_distorted_4k_crop", both, ref_cam(3840, 2160), 3840, 2160, po.VARIANT_MESH, geo, [1, 4], (2585, 200, 64, 64))]
+
+
+def only(names):
+    """Generates the named cases and leaves every other fixture as it is (python3 oracle/gen_golden.py --only a,b)."""
+    path = f"{GOLD}/generation_report.json"
+    report = json.load(open(path)) if os.path.exists(path) else []
+    for (name, sc, cam, W, H, variant, nm, spp, crop) in config4_cases():
+        if name not in names:
+            continue
+        fx, rep = render_case(name, sc, cam, W, H, variant, nm, spp, crop)
+        np.savez_compressed(f"{GOLD}/case_{name}.npz", **fx)
+        report = [r for r in report if r.get("case") != name] + [rep]
+    json.dump(report, open(path, "w"), indent=1)
+
+
 def main():
+    if len(sys.argv) >= 3 and sys.argv[1] == "--only":
+        return only(sys.argv[2].split(","))
     os.makedirs(GOLD, exist_ok=True)
     os.makedirs(ASSETS_DIR, exist_ok=True)
     report = []
@@ -283,6 +319,11 @@ def main():
               ("cornell_materials_1080p_crop", cornell_m, ccam(1920, 1080), 1920, 1080, [1, 4], (700, 300, 64, 64))]
     for (name, sc, cam, W, H, spp, crop) in mcases:
         fx, rep = render_case(name, sc, cam, W, H, po.VARIANT_MESH, po.NORMALS_GEOMETRIC, spp, crop, shading_mode=1)
+        np.savez_compressed(f"{GOLD}/case_{name}.npz", **fx)
+        report.append(rep)
+
+    for (name, sc, cam, W, H, variant, nm, spp, crop) in config4_cases():
+        fx, rep = render_case(name, sc, cam, W, H, variant, nm, spp, crop)
         np.savez_compressed(f"{GOLD}/case_{name}.npz", **fx)
         report.append(rep)
 

@@ -59,10 +59,36 @@ def instanced_mesh(vertices, indices, instances=254, columns=16, spacing=2.8, un
     return out_v, out_i
 
 
+def distorted_copy(vertices, amplitude=0.12, offset=(0.0, 0.0, 0.0), seed=20260101):
+    """A deterministically distorted copy of a mesh: every vertex moved by up to `amplitude` along each axis with offsets
+    from the fixed LCG stream (integer arithmetic, so the same on every machine), then translated by `offset`. Stands in
+    for the reference's data/distordedmesh/*.bin, a container that nothing in the reference loads. Returns vertices6."""
+    v = np.asarray(vertices, np.float32).reshape(-1, 6).astype(np.float64)
+    rnd = _lcg_uniform(len(v) * 3, seed).reshape(len(v), 3)
+    out = np.zeros((len(v), 6), np.float32)
+    out[:, :3] = (v[:, :3] + (rnd - 0.5) * (2.0 * amplitude) + np.asarray(offset, np.float64)).astype(np.float32)
+    return out
+
+
+def torus_with_distorted_copy(vertices, indices, separation=1.4):
+    """The torus moved `separation` to the left, and its distorted copy the same distance to the right: one mesh of twice the
+    triangles (ids of the copy follow those of the original). Edges are about 0.3-1 unit long, far above what the shader's
+    absolute `det >= 1e-4` cull removes."""
+    v = np.asarray(vertices, np.float32).reshape(-1, 6)
+    idx = np.asarray(indices, np.uint32).reshape(-1, 3)
+    left = v.copy()
+    left[:, 0] = (left[:, 0].astype(np.float64) - separation).astype(np.float32)
+    right = distorted_copy(v, offset=(separation, 0.0, 0.0))
+    return np.concatenate([left, right]), np.concatenate([idx, idx + np.uint32(len(v))])
+
+
 class SceneData:
     def __init__(self, name, width=None, height=None):
         if name == "instanced":
             self._init_instanced(width, height)
+            return
+        if name == "torus_distorted":
+            self._init_torus_distorted(width, height)
             return
         obj, view, program, w0, h0 = WORKLOADS[name]
         self.name, self.program = name, program
@@ -95,6 +121,22 @@ class SceneData:
                                         [0.8, 0.8, 0.3, 0], [0.3, 0.8, 0.8, 0], [0.8, 0.3, 0.8, 0], [1.0, 0.9, 0.7, 6.0]], np.float32)
         self.normal_mode = capi.NORMALS_GEOMETRIC
         self.camera = host_api.camera(60.0, self.width, self.height, (0.0, 0.0, -44.0 * unit), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0))
+        self.spheres, self.materials = host_api.reference_spheres()
+        self.num_triangles = len(self.indices)
+
+    def _init_torus_distorted(self, width, height):
+        """BASELINE configuration 4: catmark_torus_creases0.obj next to a distorted copy of itself, 3840x2160, the
+        reference's camera and its z + 3 translation, geometric normals (the file has no vn)."""
+        self.name, self.program = "torus_distorted", capi.PROGRAM_MESH
+        self.width, self.height = width or 3840, height or 2160
+        o = host_api.ObjFile(os.path.join(ASSETS, "catmark_torus_creases0.obj"), ASSETS + "/")
+        base = o.mesh_default
+        self.vertices, self.indices = torus_with_distorted_copy(base["vertices"], base["indices"])
+        self.material_table = np.array([[0.75, 0.75, 0.75, 0], [0.3, 0.6, 0.8, 0]], np.float32)
+        self.material_ids = (np.arange(len(self.indices)) >= len(base["indices"])).astype(np.int32)
+        self.normal_mode = capi.NORMALS_GEOMETRIC
+        v = REFERENCE_VIEW
+        self.camera = host_api.camera(v["fov"], self.width, self.height, v["eye"], v["target"], v["up"])
         self.spheres, self.materials = host_api.reference_spheres()
         self.num_triangles = len(self.indices)
 

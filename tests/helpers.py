@@ -8,7 +8,9 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = ["monkey_mesh_128", "monkey_mesh_160x90", "monkey_mesh_1080p_crop", "world_128", "world_1280x720_crop",
          "cornell_geo_128", "cornell_geo_1080p_crop", "suzanne_geo_96",
          # build-defined diffuse/emissive mode: llvmpipe ran the reference shader with oracle/llvmpipe/edits/mesh_materials_geo.txt
-         "cornell_materials_128", "cornell_materials_1080p_crop"]
+         "cornell_materials_128", "cornell_materials_1080p_crop",
+         # BASELINE configuration 4: the torus, and the torus next to its deterministically distorted copy
+         "torus_geo_128", "torus_distorted_geo_128", "torus_distorted_geo_256x144", "torus_distorted_4k_crop"]
 
 
 def case_shading_mode(fx):

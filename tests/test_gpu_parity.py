@@ -648,3 +648,79 @@ def test_sample_split_over_eight_at_full_size():
         assert np.abs(total * np.float32(1.0 / 1024.0) - mean).max() < 2e-6
     finally:
         t.close()
+
+
+CONFIG4 = ["torus_geo_128", "torus_distorted_geo_128", "torus_distorted_geo_256x144", "torus_distorted_4k_crop"]
+
+
+@pytest.mark.parametrize("accel", [1, 2, 4])
+@pytest.mark.parametrize("name", CONFIG4)
+def test_config4_goldens_through_every_search_mode(tracer, name, accel):
+    """BASELINE configuration 4 (catmark torus + its distorted copy) against what the reference shader rendered on llvmpipe,
+    through the all-triangles loop, the LBVH and the direction grid: ids, distances and radiance bit for bit, the latter from one
+    multi-sample dispatch per checkpoint."""
+    fx = load_case(name)
+    t = tracer
+    prog = setup_case(t, fx)
+    t.build_accel()
+    t.set_accel_mode(accel)
+    x0, y0, w, h = (int(v) for v in fx["crop"])
+    t.set_window(x0, y0, w, h)
+    win = (slice(y0, y0 + h), slice(x0, x0 + w))
+    ids, ts = t.readback_primary()
+    assert np.array_equal(ids[win], fx["lp_id"])
+    hit = fx["lp_id"] >= 0
+    assert hit.any() and (~hit).any()
+    assert n_bit_mismatch(ts[win][hit], fx["lp_t"][hit]) == 0
+    done = 0
+    for k in sorted(int(s) for s in fx["spp"]):
+        t.dispatch(done + 1, k - done, 1)
+        t.finish()
+        done = k
+        assert n_bit_mismatch(t.readback()[win][..., :3], fx[f"lp_rgb_{k}"]) == 0, f"radiance after {k} passes"
+    t.set_accel_mode(0)
+    t.set_window()
+    t.program_destroy(prog)
+
+
+@pytest.mark.parametrize("count", [2, 4, 8])
+def test_config4_row_partition_at_full_size(count):
+    """Configuration 4 as it is meant to run: the torus and its distorted copy at 3840x2160, the rows shared by 2, 4 or 8
+    renderers in interleaved blocks of 16 (pt_set_row_interleave; what `bench.py --partition tile` gives each GPU). Every
+    part's rows are bit for bit those of the single-renderer frame, the parts together are that frame, and its crop is what
+    the reference shader rendered there on llvmpipe."""
+    from pathtracer_amd import Tracer, dist as ptdist
+    from pathtracer_amd.scenes import SceneData
+    fx = load_case("torus_distorted_4k_crop")
+    scene = SceneData("torus_distorted")
+    assert (scene.width, scene.height) == (3840, 2160)
+    assert n_bit_mismatch(scene.vertices, fx["vertices"]) == 0 and np.array_equal(scene.indices, fx["indices"])
+    W, H, spp = scene.width, scene.height, 4
+    t = Tracer(0)
+    try:
+        scene.upload(t)
+        t.target_create(W, H)
+        t.dispatch(1, spp, 1)
+        t.finish()
+        full = t.readback()
+        x0, y0, w, h = (int(v) for v in fx["crop"])
+        assert n_bit_mismatch(full[y0:y0 + h, x0:x0 + w, :3], fx["lp_rgb_4"]) == 0
+        merged = np.zeros_like(full)
+        samples = 0
+        for index in range(count):
+            t.set_row_interleave(16, index, count)
+            t.target_clear()
+            t.reset_stats()
+            t.dispatch(1, spp, 1)
+            t.finish()
+            part = t.readback()
+            own = np.zeros(H, bool)
+            for r0, rh in ptdist.row_blocks(index, count, H, 16):
+                own[r0:r0 + rh] = True
+            assert np.all(part[~own][..., :3] == 0)
+            merged[own] = part[own]
+            samples += t.stats()["samples"]
+        assert n_bit_mismatch(merged, full) == 0
+        assert samples == W * H * spp
+    finally:
+        t.close()

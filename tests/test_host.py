@@ -173,3 +173,20 @@ def test_shader_stage_selection(tmp_path):
     assert host.shader_stage_for_file(str(tmp_path / "nowhere" / "pathtracing.fs")) == "world"
     assert host.shader_stage_for_file("data/shaders/copy.fs") == "present"
     assert host.shader_stage_for_file("data/shaders/opaque.fs") == "none"
+
+
+def test_config4_scene_is_the_one_the_goldens_were_rendered_from():
+    """The torus + distorted-copy workload (BASELINE configuration 4) is built from a fixed integer LCG, so it is the same on
+    every machine: its arrays equal those stored with the llvmpipe goldens."""
+    import numpy as np
+    from helpers import load_case
+    from pathtracer_amd.scenes import SceneData, distorted_copy
+    fx = load_case("torus_distorted_geo_128")
+    sc = SceneData("torus_distorted")
+    assert sc.vertices.tobytes() == np.ascontiguousarray(fx["vertices"], np.float32).tobytes()
+    assert np.array_equal(sc.indices, fx["indices"]) and sc.num_triangles == 128 and len(sc.vertices) == 64
+    plain = SceneData("torus")
+    assert np.array_equal(plain.indices, fx["indices"][:64])
+    moved = np.abs(sc.vertices[32:, :3] - (plain.vertices[:, :3] + np.array([1.4, 0, 0], np.float32)))
+    assert moved.max() <= 0.12 + 1e-6 and moved.mean() > 0.02          # distorted, within the stated amplitude
+    assert np.array_equal(distorted_copy(plain.vertices), distorted_copy(plain.vertices))
