@@ -1,54 +1,227 @@
 #!/usr/bin/env python3
 """Throughput of the hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
+
+With N > 1 and no WORLD_SIZE in the environment this process only starts N children (one rank per GPU, RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_ADDR / MASTER_PORT set), relays rank 0's JSON line and exits non-zero if any child does; it never
+touches a GPU itself. Under torch.distributed.run (WORLD_SIZE already set) it is one of the ranks.
 
 A step = one pass of the hot path over one batch: `--spp` progressive samples of every pixel of the workload's frame
-(default: cornell_box.obj at 1920x1080, 256 spp -- the configuration the metric is quoted on), rendered by ONE kernel
-launch with the scene and the accumulation image resident in HBM. With N > 1 every rank renders its own residue
-class of the sample indices (weak scaling: per-GPU work is fixed) into a running sum, and the sums are merged by one
-RCCL all-reduce per step inside the timed region; the exchange of a step runs beside the rendering of the next one, and
-the last step's exchange is waited for before the clock stops.
+(default: cornell_box.obj at 1920x1080, 256 spp -- the configuration the metric is quoted on), rendered by ONE dispatch
+with the scene and the accumulation image resident in HBM. With N > 1, `--partition sample` (default): every rank renders
+its own residue class of the sample indices (weak scaling: per-GPU work is fixed) into a running sum, and the sums are
+merged by one RCCL all-reduce per step inside the timed region, beside the rendering of the next step; `--partition tile`:
+the ranks share the rows of ONE frame in interleaved blocks (strong scaling, bit-identical to one GPU), merged by an
+all-gather of the owned rows, also beside the next step.
 
 Prints one JSON line on rank 0: whole-job Mrays/s (ray = one closest-hit query = one bounce-loop iteration, the
-reference's definition), the roofline of the render kernel and a CPU baseline from the oracle on the host cores.
+reference's definition), the roofline of the render kernel from the work it executed, and a CPU baseline from the oracle.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # fp32 vector peak of the part (MI355X_MICROARCH.md): 256 CUs x 4 SIMD x 32 lanes x 2.4 GHz x 2 flop (FMA).
-PEAK_FP32_VALU_TFLOPS = 157.3
-# The numerics contract forbids fusing a*b+c (the reference's software GL does not fuse), so a multiply and an add
-# are two instructions: the ceiling for THIS arithmetic is half the FMA peak.
-PEAK_FP32_UNFUSED_TFLOPS = PEAK_FP32_VALU_TFLOPS / 2
+PEAK_FP32_FMA_TFLOPS = 157.3
+# The numerics contract forbids fusing a*b+c (the reference's software GL does not fuse), so a multiply and an add are
+# two instructions: the ceiling for THIS arithmetic is one fp32 operation per lane and issue slot, half the FMA peak.
+PEAK_FP32_UNFUSED_TFLOPS = PEAK_FP32_FMA_TFLOPS / 2
 # Algorithmic work of one ray-triangle test as the shader writes it (pathtracing.fs:136-151): 43 flop, mul and add
-# counted separately; flop per ray = 43 x triangles.
-FLOP_PER_TRI_TEST = 43
+# counted separately; the shader's loop costs 43 x triangles per ray. Reported as `brute_force_equivalent`, never as `frac`.
+FLOP_PER_TRI_TEST_SHADER = 43
+
+# fp32 operations per event AS EXECUTED by the kernels, counted at source level in pt_kernels.hip (add, sub, mul, floor,
+# min, max, division, reciprocal and square root one each, a fused multiply-add two; compares, selects, conversions, moves,
+# integer and address arithmetic are not counted, and a division or square root counts as ONE although it issues 4-9
+# instructions). Events come from the kernel's own counters (PtStats).
+FLOP = {
+    "rand01": 15,           # Rng::rand01: 4 add, 3 (2 mul + add), 2 fract (floor + sub), 1 mul, add, floor + sub
+    "normalize": 10,        # dot3 (3 mul + 2 add), sqrt, reciprocal, 3 mul
+    "cross": 9,
+    "reflect": 12,          # dot3, 2*, 3 mul, 3 sub
+    "pow": 42,              # lp_log2 25 (quotient 12, polynomial 13) + mul + lp_exp2 16
+    "sincos_pair": 32,      # lp_sincos<true> and <false> of one angle: shared reduction and both polynomials 28, two selections 4
+    "exp2": 16,
+    # shade(): reflect 12, two rand01 30, tangent frame 2 x (cross 9 + normalize 10) 38, pow 42, sin_t 4, phi 2, sincos 32,
+    # hemi 2, new direction 15, dot(N, rd) 5, clamps 4, Fresnel exp2 16 + 4, specular 3, throughput 2  -> 211
+    "shade_reference": 211,
+    # shade_materials(), Lambert branch: hit point 6, two rand01 30, tangent frame 38, pow 42, sin_t 4, phi 2, sincos 32, hemi 2,
+    # new direction 15, new origin 6, throughput 3 -> 180 (the emitter branch is 6)
+    "shade_materials": 180,
+    "vertex_normal": 29,    # mesh_normal(): barycentrics 4, blend 15, normalize 10 (not for geometric normals)
+    "sample_end": 21,       # sky 12 (fs:408-410), running mean 9 (fs:414)
+    "grid_query": 9,        # reciprocal of the major axis, 2 x (mul, add, mul, floor)
+    "test_origin_records": 25,  # test against an origin-relative record: cross 9, det 5, u 5, v 5, u + v 1
+    "test_accept": 2,       # 1/det, t
+    "test_from_first": 14,  # rays with their own origin: cross 9, det 5 (always) ...
+    "test_from_rest": 23,   # ... ap 3, cross 9, u 5, v 5, u + v 1 (past the wave-uniform back-face skip)
+    "loop_first": 14,       # all-triangles loop over origin-relative records: cross 9 + det 5 (always) ...
+    "loop_rest": 11,        # ... u 5, v 5, u + v 1 (past the skip)
+    "spheres_query": 70,    # 10 x (dot3 5, B*B - C 2)
+    "sphere_accept": 15,    # sqrt, two roots, hit point 6, normal 6
+}
+
+# Where a gather-bound walk's records come from, by their footprint (MI355X_MICROARCH.md, "Indexed rows" and "L2"):
+# random rows out of the XCD's L2, out of the Infinity Cache, out of HBM (GB/s chip-wide).
+GATHER_PEAK = (("l2", 4 << 20, 16800.0), ("infinity_cache", 256 << 20, 8600.0), ("hbm", 1 << 62, 8000.0))
 
 
-def cpu_baseline(scene, spp_hint, budget_s=25.0):
+def kernel_source_hash():
+    """Identifies the kernels a profile was taken from: sources + build flags."""
+    h = hashlib.sha256()
+    for rel in ("pathtracer_amd/csrc/pt_kernels.hip", "pathtracer_amd/csrc/pt_internal.h", "pathtracer_amd/csrc/pt_grid.hip",
+                "pathtracer_amd/csrc/pt_bvh.hip"):
+        h.update(open(os.path.join(ROOT, rel), "rb").read())
+    from pathtracer_amd import build as ptbuild
+    h.update(" ".join(ptbuild.DEVICE_FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
+PMC_SIDECAR = os.path.join(ROOT, "profiles", "r02_pmc.json")
+
+
+def config_key(workload, width, height, spp, shading, accel):
+    return f"{workload}|{width}x{height}|{spp}spp|{shading}|{accel}"
+
+
+def pmc_entry(key):
+    """Counter-derived figures for this exact configuration from the tracked profile written by tools/pmc_collect.py, or
+    None when there is none or it was taken from other kernel sources."""
+    try:
+        doc = json.load(open(PMC_SIDECAR))
+    except (OSError, ValueError):
+        return None, "no profiles/r02_pmc.json"
+    e = doc.get("entries", {}).get(key)
+    if e is None:
+        return None, "no PMC profile of this configuration"
+    if e.get("kernel_hash") != kernel_source_hash():
+        return None, f"PMC profile is stale (taken from kernel sources {e.get('kernel_hash')}, now {kernel_source_hash()})"
+    return e, None
+
+
+def which_kernel(st, program, shading):
+    if program == 0:
+        return "pt_render_kernel<0,false>", "spheres"
+    if shading == "materials":
+        if st["grid_triangle_tests"] > 0:
+            return "pt_render_kernel<5,true>", "lane_walk"
+        if st["bvh_node_fetches"] > 0:
+            return "pt_render_kernel<2,true>", "wave_walk"
+        return "pt_render_kernel<1,true>", "loop_from"
+    if st["grid_triangle_tests"] > 0:
+        return "pt_render_kernel<4,false>", "grid"
+    if st["bvh_node_fetches"] > 0:
+        return "pt_render_kernel<2,false>", "wave_walk"
+    return "pt_render_kernel<1,false>", "loop"
+
+
+def roofline(st, kernel_ms, scene, shading, pmc, pmc_note):
+    """The render kernel against the ceiling that bounds it, from the work it executed in the timed launches."""
+    n = max(1, st["dispatches"])
+    per = {k: st[k] / n for k in ("rays", "rays_traced", "samples", "lane_slots", "bvh_node_fetches", "bvh_triangle_fetches",
+                                  "grid_triangle_tests", "shaded_hits", "loop_triangle_visits", "loop_full_tests")}
+    kernel, kind = which_kernel(st, scene.program, shading)
+    sec = kernel_ms * 1e-3
+    lane_util = per["rays_traced"] / per["lane_slots"] if per["lane_slots"] else 0.0
+    out = {"kernel": kernel, "kernel_ms": kernel_ms, "lane_utilisation": lane_util,
+           "events_per_launch": {k: v for k, v in per.items() if v}}
+    brute = per["rays_traced"] * FLOP_PER_TRI_TEST_SHADER * scene.num_triangles
+    if kind in ("wave_walk", "lane_walk"):
+        # dependent record fetches: 64-byte node and triangle records. Per-wave walk: one scalar fetch serves the wave;
+        # per-lane walk: every lane gathers its own.
+        recs = per["grid_triangle_tests"] if kind == "lane_walk" else per["bvh_node_fetches"] + per["bvh_triangle_fetches"]
+        nbytes = recs * 64.0
+        footprint = scene.num_triangles * 128     # node + triangle record per triangle
+        level, _, peak = next(g for g in GATHER_PEAK if footprint <= g[1])
+        gbs = nbytes / sec * 1e-9 if sec > 0 else 0.0
+        out.update({"bound": level if level != "hbm" else "hbm", "achieved": gbs, "peak": peak, "unit": "GB/s", "frac": gbs / peak,
+                    "hbm_peak": 8000.0, "frac_of_hbm_peak": gbs / 8000.0,
+                    "algorithmic_bytes_per_launch": nbytes, "records_footprint_bytes": footprint,
+                    "records_per_evaluated_query": recs / per["rays_traced"] if per["rays_traced"] else 0.0,
+                    "note": "bytes = 64-byte node and triangle records fetched by the hierarchy walk (counted in-kernel: "
+                            + ("per lane" if kind == "lane_walk" else "once per wave, scalar fetches") +
+                            "), priced against the random-row gather rate of the level their footprint fits "
+                            "(MI355X_MICROARCH.md: L2 16.8, Infinity Cache 8.6, HBM 8.0 TB/s)"})
+    else:
+        shade = FLOP["shade_materials"] if shading == "materials" else FLOP["shade_reference"]
+        if scene.program != 0 and scene.normal_mode == 0:
+            shade += FLOP["vertex_normal"]
+        flop = per["shaded_hits"] * shade + per["samples"] * FLOP["sample_end"]
+        if kind == "grid":
+            flop += per["rays_traced"] * FLOP["grid_query"] + per["grid_triangle_tests"] * FLOP["test_origin_records"]
+            flop += per["shaded_hits"] * FLOP["test_accept"]
+        elif kind == "spheres":
+            flop += per["rays_traced"] * FLOP["spheres_query"] + per["shaded_hits"] * FLOP["sphere_accept"]
+        else:
+            # records visited per wave trip x the lanes that wanted a hit (the others are masked off)
+            per_lane_tests = per["loop_triangle_visits"] * 64.0 * lane_util
+            first, rest = (FLOP["test_from_first"], FLOP["test_from_rest"]) if kind == "loop_from" else (FLOP["loop_first"], FLOP["loop_rest"])
+            past_skip = per["loop_full_tests"] / per["loop_triangle_visits"] if per["loop_triangle_visits"] else 0.0
+            flop += per_lane_tests * (first + rest * past_skip) + per["shaded_hits"] * FLOP["test_accept"]
+            out["loop_tests_past_backface_skip"] = past_skip if per["loop_full_tests"] else \
+                "not counted in the product build: only the part of a test before the skip is priced"
+        tf = flop / sec * 1e-12 if sec > 0 else 0.0
+        out.update({"bound": "valu", "achieved": tf, "peak": PEAK_FP32_UNFUSED_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_UNFUSED_TFLOPS,
+                    "peak_fma_nominal": PEAK_FP32_FMA_TFLOPS, "frac_of_fma_nominal": tf / PEAK_FP32_FMA_TFLOPS,
+                    "executed_flop_per_launch": flop,
+                    "note": "achieved = fp32 operations the kernel executed (events counted in-kernel x operations per event counted in "
+                            "pt_kernels.hip, bench.py FLOP table; a division or square root counts as one, compares/selects/moves/integer "
+                            "work as none) / kernel time; peak = the fp32 rate without fused multiply-add, which the numerics contract "
+                            "forbids (half of the nominal 157.3)"})
+    out["brute_force_equivalent"] = {"TFLOP_per_s": brute / sec * 1e-12 if sec > 0 else 0.0, "frac_algorithmic": brute / sec * 1e-12 / PEAK_FP32_FMA_TFLOPS if sec > 0 else 0.0,
+                                     "note": "evaluated queries x 43 x triangles: what the shader's own all-triangles loop would execute for the "
+                                             "same queries; not work this kernel does"}
+    out["traffic"] = None
+    if pmc is not None:
+        out["traffic"] = pmc.get("hbm_bytes_per_launch")
+        out["pmc"] = {k: pmc[k] for k in ("source", "kernel_hash", "valu_insts_per_launch", "valu_issue_share", "valu_lane_ops_frac_of_unfused_peak",
+                                          "active_lane_share_of_valu", "fp32_share_of_valu_insts", "hw_fp32_flop_per_launch_active_lanes",
+                                          "wait_inst_share", "wait_any_share", "l2_hit_rate", "fetch_bytes_per_launch", "write_bytes_per_launch",
+                                          "kernel_ms", "kernel_ms_rocprof_stats_avg") if k in pmc}
+        if out["traffic"] and sec > 0:
+            out["hbm_GB_per_s"] = out["traffic"] / (pmc.get("kernel_ms", kernel_ms) * 1e-3) * 1e-9
+            out["hbm_frac"] = out["hbm_GB_per_s"] / 8000.0
+    else:
+        out["pmc"] = pmc_note
+    return out
+
+
+def cpu_baseline(scene, spp_hint, shading, budget_s=25.0):
     """The oracle (CPU restatement of the reference shader) on the same scene/camera/resolution, on a bounded sample:
     the full frame for as many passes as fit the time budget."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pt_oracle as po
     threads = min(16, os.cpu_count() or 1)
-    sc = po.Scene(scene.vertices, scene.indices, scene.spheres, scene.materials)
+    if shading == "materials":
+        sc = po.Scene(scene.vertices, scene.indices, scene.spheres, scene.material_table, scene.material_ids)
+    else:
+        sc = po.Scene(scene.vertices, scene.indices, scene.spheres, scene.materials)
     u = po.uniforms(scene.camera, scene.width, scene.height, scene.num_triangles, 10,
-                    po.VARIANT_MESH if scene.program == 1 else po.VARIANT_WORLD, scene.normal_mode)
-    # calibrate on a strip, then run whole-frame passes within the budget
+                    po.VARIANT_MESH if scene.program == 1 else po.VARIANT_WORLD, scene.normal_mode,
+                    po.SHADE_MATERIALS if shading == "materials" else po.SHADE_REFERENCE)
+    # calibrate on a strip, then run whole-frame passes within the budget (a large mesh: a strip only). The oracle tests
+    # every triangle for every ray, about 2e9 tests per second on these threads: the strip is sized for about ten seconds
     strip = max(8, scene.height // 16)
+    if scene.program == 1 and scene.num_triangles > 0:
+        strip = int(max(1, min(strip, 2.0e10 / scene.num_triangles / 1.5 // scene.width)))
+    win = (0, (scene.height - strip) // 2, scene.width, strip)
     t0 = time.perf_counter()
-    _, rays = po.render(sc, u, 1, 1, window=(0, (scene.height - strip) // 2, scene.width, strip), threads=threads)
+    _, rays = po.render(sc, u, 1, 1, window=win, threads=threads)
     dt = time.perf_counter() - t0
     per_pass = dt * scene.height / strip
+    if per_pass > budget_s:
+        return {"value": rays / dt * 1e-6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+                "sample": f"{scene.name} {scene.width}x{scene.height}, pass 1 of the middle {strip} rows, {rays} rays in {dt:.2f} s "
+                          f"(oracle/pt_oracle.c, {threads} threads; a whole pass would take {per_pass:.0f} s)"}
     passes = int(max(1, min(spp_hint, budget_s / max(per_pass, 1e-6))))
     t0 = time.perf_counter()
     _, rays = po.render(sc, u, 1, passes, threads=threads)
@@ -64,7 +237,7 @@ def trace(msg):
         print(f"[bench rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -73,18 +246,112 @@ def main():
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--spp", type=int, default=256, help="samples per pixel per step and per GPU")
+    ap.add_argument("--shading", default="reference", choices=["reference", "materials"],
+                    help="'reference' = the shader as committed; 'materials' = the diffuse/emissive mode with the scene's MTL-derived table")
+    ap.add_argument("--accel", default="auto", choices=["auto", "brute", "bvh", "grid"])
     ap.add_argument("--partition", default="sample", choices=["sample", "tile"],
                     help="with --gpus N > 1: 'sample' = every GPU renders its own --spp samples of the whole frame (weak scaling, "
                          "all-reduce of sums); 'tile' = the GPUs share the rows of ONE frame of --spp samples in interleaved blocks "
-                         "(strong scaling, bit-identical to one GPU, merged by an exact sum)")
+                         "(strong scaling, bit-identical to one GPU, merged by an all-gather of the owned rows)")
+    ap.add_argument("--dump-image", default=None, help="rank 0 writes the last step's merged image ([H, W, 4] float32 .npy) here")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-second-scene", action="store_true", help="skip the short 1M-triangle run reported under 'large_scene'")
-    ap.add_argument("--lean", action="store_true", help="warm-up and timed steps only (no CPU baseline, no 1M-triangle run, no "
+    ap.add_argument("--no-second-scene", action="store_true", help="skip the short 1M-triangle and materials runs reported beside the headline")
+    ap.add_argument("--lean", action="store_true", help="warm-up and timed steps only (no CPU baseline, no second scenes, no "
                     "no-reuse comparison): what to put behind rocprofv3 so that the kernel statistics cover exactly these launches")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     if args.lean:
         args.no_cpu_baseline = args.no_second_scene = True
+    return args
 
+
+def launch_ranks(args):
+    """--gpus N > 1 started directly: N child processes, one per GPU, before this process has touched a GPU (it never does).
+    Returns the exit code: 0 only if every rank exited 0; rank 0's stdout (the JSON line) is relayed."""
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in env:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            env["MASTER_PORT"] = str(s.getsockname()[1])
+    env["WORLD_SIZE"] = str(args.gpus)
+    procs = []
+    for r in range(args.gpus):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    # rank 0's stdout (one JSON line at its end) is read by a thread, so its pipe can never fill up
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    code = 0
+    pending = set(range(args.gpus))
+    while pending:
+        for r in sorted(pending):
+            rc = procs[r].poll()
+            if rc is not None:
+                pending.discard(r)
+                if rc != 0:
+                    code = code or rc
+                    print(f"[bench] rank {r} exited with {rc}", file=sys.stderr, flush=True)
+        if code and pending:
+            # a failed rank leaves the others waiting in a collective: give them a moment, then end them
+            deadline = time.time() + 5.0
+            while time.time() < deadline and any(procs[r].poll() is None for r in pending):
+                time.sleep(0.1)
+            for r in pending:
+                if procs[r].poll() is None:
+                    procs[r].terminate()
+            for r in pending:
+                try:
+                    procs[r].wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+            break
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    out0 = out0[0] if out0 else b""
+    sys.stdout.write(out0.decode("utf-8", "replace"))
+    sys.stdout.flush()
+    return code
+
+
+def side_run(local_rank, workload, shading, spp, steps, width=None, height=None):
+    """A short run of another configuration on rank 0, outside the timed region: mean of `steps` dispatches after two warm-ups."""
+    from pathtracer_amd import Tracer
+    from pathtracer_amd.scenes import SceneData
+    sc = SceneData(workload, width, height)
+    t = Tracer(local_rank)
+    sc.upload(t, shading=shading)
+    t.target_create(sc.width, sc.height)
+    t.enable_timing(True)
+    for _ in range(2):          # from the second dispatch on the work list rests on measured tile costs
+        t.target_clear()
+        t.dispatch(1, spp, 1)
+    t.finish()
+    t.reset_stats()
+    for _ in range(steps):      # includes the scheduler runs that fall into this stretch (the list is rebuilt now and then)
+        t.target_clear()
+        t.dispatch(1, spp, 1)
+    t.finish()
+    st = t.stats()
+    t.close()
+    ms = st["total_dispatch_ms"] / max(1, st["dispatches"])
+    key = config_key(workload, sc.width, sc.height, spp, shading, "auto")
+    pmc, note = pmc_entry(key)
+    n = max(1, st["dispatches"])
+    return {"workload": f"{sc.name} {sc.width}x{sc.height}, {sc.num_triangles} triangles, {spp} spp per dispatch, shading {shading} (mean of {steps} dispatches)",
+            "Mrays_per_s": st["rays"] / n / ms * 1e-3, "evaluated_Mrays_per_s": st["rays_traced"] / n / ms * 1e-3,
+            "kernel_ms": ms, "rays_per_sample": st["rays"] / max(1, st["samples"]),
+            "roofline": roofline(st, ms, sc, shading, pmc, note)}
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+
+    import numpy as np
     import torch
     import torch.distributed as dist
     from pathtracer_amd import Tracer, capi, dist as ptdist
@@ -94,11 +361,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
-        # the CPU baseline, the 1M-triangle run and the no-reuse comparison are reported by the single-GPU run only
+        # the CPU baseline, the second scenes and the no-reuse comparison are reported by the single-GPU run only
         # (they happen after the timed region on rank 0 and would keep the other ranks waiting at the final barrier)
         args.no_cpu_baseline = args.no_second_scene = args.lean = True
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
     # Rehearsal knobs for a one-GPU box (never set by the driver): PT_BENCH_SHARE_GPU=1 puts every rank on device 0 and
@@ -124,8 +391,9 @@ def main():
     tracer = Tracer(local_rank)
     stream = torch.cuda.Stream(device=device)
     tracer.set_stream(stream.cuda_stream)
-    scene.upload(tracer)
-    # the accumulation image lives in a torch tensor so that RCCL can reduce it in place
+    scene.upload(tracer, shading=args.shading)
+    tracer.set_accel_mode({"auto": capi.ACCEL_AUTO, "brute": capi.ACCEL_BRUTE, "bvh": capi.ACCEL_BVH, "grid": capi.ACCEL_GRID}[args.accel])
+    # the accumulation image lives in a torch tensor so that RCCL can work on it in place
     image = torch.zeros((H, W, 4), dtype=torch.float32, device=device)
     tracer.target_bind_external(image.data_ptr(), image.data_ptr(), W, H)
     sample_split = world > 1 and args.partition == "sample"
@@ -137,15 +405,18 @@ def main():
     else:
         first, stride, count = ptdist.sample_indices(rank, world, spp * world)
     tracer.enable_timing(True)
-    # the exchange of a frame's sums runs beside the rendering of the next frame (PT_BENCH_OVERLAP=0: in line, as one step)
+    # the exchange of a frame runs beside the rendering of the next frame (PT_BENCH_OVERLAP=0: in line, as one step)
+    overlap = os.environ.get("PT_BENCH_OVERLAP", "1") != "0"
     merger = None
-    if sample_split and os.environ.get("PT_BENCH_OVERLAP", "1") != "0":
+    if sample_split and overlap:
         merger = ptdist.OverlappedSampleMerge(image, spp * world)
+    gather = ptdist.TileGather(image, rank, world, 16, overlapped=overlap) if tile_split else None
+    merged = [image]
 
     def step():
         with torch.cuda.stream(stream):
             image.zero_()
-            if not sample_split and not tile_split:
+            if not sample_split:
                 image[..., 3] = 1.0
             tracer.dispatch(first, count, stride)
             if merger is not None:
@@ -153,12 +424,14 @@ def main():
             elif sample_split:
                 ptdist.merge_sample_split(image, spp * world)
             elif tile_split:
-                ptdist.merge_tile_split(image, H)   # rows of other ranks are zero here: the sum moves bytes, nothing else
+                gather.submit(image)   # owned rows travel; nothing is added
 
     def fence():
-        if merger is not None:
-            with torch.cuda.stream(stream):
-                merger.finish()   # the last frame's exchange belongs to the timed region
+        with torch.cuda.stream(stream):
+            if merger is not None:
+                merged[0] = merger.finish()   # the last frame's exchange belongs to the timed region
+            if gather is not None:
+                merged[0] = gather.finish()
         stream.synchronize()
         torch.cuda.synchronize(device)
         if world > 1:
@@ -179,6 +452,8 @@ def main():
     elapsed = time.perf_counter() - t0
     trace("timed steps done")
     st = tracer.stats()
+    if args.dump_image and rank == 0:
+        np.save(args.dump_image, merged[0].detach().cpu().numpy())
 
     # the same steps with the camera ray evaluated for every sample, as the shader does (outside the timed region, for the record)
     plain, plain_elapsed = None, 0.0
@@ -197,52 +472,32 @@ def main():
         tracer.set_primary_reuse(True)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    counts = torch.tensor([float(st["rays"]), float(st["samples"])], dtype=torch.float64, device=device)
+    counts = torch.tensor([float(st["rays"]), float(st["samples"]), float(st["rays_traced"])], dtype=torch.float64, device=device)
     if world > 1:
+        if backend != "nccl":
+            t, counts = t.cpu(), counts.cpu()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
     elapsed = float(t.item())
-    rays, samples = float(counts[0].item()), float(counts[1].item())
+    rays, samples, traced = float(counts[0].item()), float(counts[1].item()), float(counts[2].item())
 
-    # second half of the headline metric: the ~1M-triangle scene through the LBVH (short run, rank 0, outside the timed region)
-    large = None
-    if rank == 0 and not args.no_second_scene and args.workload != "instanced":
-        big = SceneData("instanced")
-        t2 = Tracer(local_rank)
-        big.upload(t2)
-        t2.target_create(big.width, big.height)
-        t2.enable_timing(True)
-        big_spp = 256               # per dispatch; the configuration's 4096 spp would be sixteen of these
-        for _ in range(2):          # warm-up: from the second dispatch on the work list rests on measured tile costs
-            t2.target_clear()
-            t2.dispatch(1, big_spp, 1)
-        t2.finish()
-        t2.reset_stats()
-        for _ in range(8):          # includes the scheduler runs that fall into this stretch (the list is rebuilt now and then)
-            t2.target_clear()
-            t2.dispatch(1, big_spp, 1)
-        t2.finish()
-        s2 = t2.stats()
-        s2 = dict(s2, last_dispatch_ms=s2["total_dispatch_ms"] / s2["dispatches"], rays=s2["rays"] / s2["dispatches"],
-                  rays_traced=s2["rays_traced"] / s2["dispatches"],
-                  samples=s2["samples"] / s2["dispatches"], lane_slots=s2["lane_slots"] / s2["dispatches"],
-                  bvh_node_fetches=s2["bvh_node_fetches"] / s2["dispatches"], bvh_triangle_fetches=s2["bvh_triangle_fetches"] / s2["dispatches"])
-        large = {"workload": f"instanced suzanne x254, {big.num_triangles} triangles, {big.width}x{big.height}, {big_spp} spp per dispatch, direction grid (PT_ACCEL_AUTO; mean of 8 dispatches)",
-                 "Mrays_per_s": s2["rays"] / s2["last_dispatch_ms"] * 1e-3, "traced_Mrays_per_s": s2["rays_traced"] / s2["last_dispatch_ms"] * 1e-3,
-                 "kernel_ms": s2["last_dispatch_ms"],
-                 "rays_per_sample": s2["rays"] / s2["samples"],
-                 "triangle_tests_per_evaluated_query": s2["grid_triangle_tests"] / max(1, s2["dispatches"]) / max(1, s2["rays_traced"]),
-                 "grid_list_entries": s2["grid_entries"],
-                 "gathered_GB_per_s": (s2["grid_triangle_tests"] / max(1, s2["dispatches"]) * 68 + s2["rays_traced"] * 8) / (s2["last_dispatch_ms"] * 1e-3) * 1e-9,
-                 "brute_force_equivalent_TFLOP_per_s": s2["rays_traced"] * FLOP_PER_TRI_TEST * big.num_triangles / (s2["last_dispatch_ms"] * 1e-3) * 1e-12}
-        t2.close()
+    # second half of the headline metric (the ~1M-triangle scene) and the shading the north star names (diffuse/emissive
+    # materials): short runs on rank 0, outside the timed region
+    large = materials = materials_large = None
+    if rank == 0 and not args.no_second_scene:
+        if args.workload != "instanced":
+            large = side_run(local_rank, "instanced", "reference", 256, 8)
+        if args.shading != "materials":
+            materials = side_run(local_rank, "cornell", "materials", 256, 4)
+            materials_large = side_run(local_rank, "instanced", "materials", 16, 4)
 
     if rank == 0:
         kernel_ms = st["total_dispatch_ms"] / max(1, st["dispatches"])
-        # the roofline prices the closest-hit queries the kernel evaluated (reused camera-ray answers cost nothing)
-        rays_per_launch = st["rays_traced"] / max(1, st["dispatches"])
-        flop_per_launch = rays_per_launch * FLOP_PER_TRI_TEST * scene.num_triangles
-        achieved = flop_per_launch / (kernel_ms * 1e-3) * 1e-12 if kernel_ms > 0 else 0.0
+        key = config_key(args.workload, W, H, spp, args.shading, args.accel)
+        pmc, pmc_note = pmc_entry(key) if world == 1 else (None, "single-GPU profile only")
+        roof = roofline(st, kernel_ms, scene, args.shading, pmc, pmc_note)
+        how = {"grid": "closest hit through the direction grid", "wave_walk": "device LBVH, one walk per wave", "lane_walk": "device LBVH, one walk per lane",
+               "loop": "the shader's loop over all triangles", "loop_from": "the shader's loop over all triangles", "spheres": "the reference's 10 spheres (IntersectWorld)"}[which_kernel(st, scene.program, args.shading)[1]]
         out = {
             "metric": "Mrays/s (whole node) at 1080p Cornell box + 1M-tri scene, 1/2/4/8 MI355X",
             "value": rays / elapsed * 1e-6,
@@ -255,79 +510,49 @@ def main():
             "scaling": "strong" if tile_split else "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": {"cornell": "synthetic camera on the reference cornell_box.obj", "instanced": "synthetic: 254 jittered instances of the reference suzanne.obj (fixed LCG seed)"}.get(args.workload, "reference OBJ asset, reference camera"),
-            "config": {"workload": f"{scene.name} {W}x{H}, {spp} spp per {'frame (one frame per step, rows shared by the GPUs)' if tile_split else 'GPU per step'}, depth 10, " +
-                                   (f"{scene.num_triangles} triangles, closest hit through the direction grid (PT_ACCEL_AUTO)"
-                                    if scene.program == 1 else "the reference's 10 spheres (IntersectWorld)"),
-                       "parallelism": "single GPU" if world == 1 else (f"image rows in interleaved blocks of 16 over {world} GPUs, merged by an exact sum (RCCL all-reduce)"
+            "data": {"cornell": "synthetic camera on the reference cornell_box.obj",
+                     "instanced": "synthetic: 254 jittered instances of the reference suzanne.obj (fixed LCG seed)",
+                     "torus_distorted": "reference catmark_torus_creases0.obj + a deterministically distorted copy of it (fixed LCG seed) standing in for "
+                                        "data/distordedmesh/*.bin, which nothing in the reference loads"}.get(args.workload, "reference OBJ asset, reference camera"),
+            "config": {"workload": f"{scene.name} {W}x{H}, {spp} spp per {'frame (one frame per step, rows shared by the GPUs)' if tile_split else 'GPU per step'}, depth 10, "
+                                   f"{scene.num_triangles if scene.program == 1 else 0} triangles, {how}, shading {args.shading}",
+                       "parallelism": "single GPU" if world == 1 else (f"image rows in interleaved blocks of 16 over {world} GPUs, merged by an all-gather of the owned rows (RCCL)" +
+                                                                           (", overlapped with the next step's rendering" if overlap else "")
                                                                            if tile_split else f"sample split over {world} GPUs + RCCL all-reduce of the sums" +
                                                                            (", overlapped with the next step's rendering" if merger is not None else ""))},
-            "rays_definition": "closest-hit queries as the reference counts them: one per bounce-loop iteration of every sample "
+            "value_evaluated": traced / elapsed * 1e-6,
+            "rays_definition": "value: closest-hit queries as the reference counts them, one per bounce-loop iteration of every sample "
                                "(PathTracer.cpp:947). The shader has no pixel jitter, so the first query of every sample of a pixel "
                                "is the same; it is evaluated once per dispatch and pixel and reused (bit-identical image). "
-                               "'rays_traced_per_s' counts only evaluated queries; 'no_primary_reuse' is the same step without the reuse.",
+                               "value_evaluated counts only the queries actually evaluated (the figure to compare across tracers); "
+                               "'no_primary_reuse' is the same step with every query evaluated.",
             "primary_reuse": True,
-            "rays_traced_per_s": st["rays_traced"] * world / elapsed if world == 1 else None,
             "no_primary_reuse": None if plain is None else
                                 {"value": plain["rays"] / 3 / plain_elapsed * 1e-6 * world, "unit": "Mrays/s", "ms_per_step": plain_elapsed * 1e3,
                                  "kernel_ms": plain["total_dispatch_ms"] / max(1, plain["dispatches"]), "note": "rank 0 clock, 3 steps after 2 warm-up steps"},
             "samples_per_s": samples / elapsed,
             "rays_per_sample": rays / samples if samples else 0.0,
-            "roofline": {
-                "bound": "valu",
-                "achieved": achieved,
-                "peak": PEAK_FP32_VALU_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP32_VALU_TFLOPS,
-                "peak_unfused": PEAK_FP32_UNFUSED_TFLOPS,
-                "frac_unfused": achieved / PEAK_FP32_UNFUSED_TFLOPS,
-                "traffic": None,
-                "kernel": "pt_render_kernel<4,false> (direction grid)" if scene.program == 1 else "pt_render_kernel<0,false> (spheres)",
-                "kernel_ms": kernel_ms,
-                "algorithmic_flop_per_launch": flop_per_launch,
-                "note": "algorithmic flop = evaluated closest-hit queries x 43 x triangles, the shader's formulation (mul and add "
-                        "counted separately; FMA is not permitted by the numerics contract); shading and RNG work is not counted. "
-                        "The kernel executes far fewer: a query tests only the triangles listed in the cube-map cell of its direction "
-                        "(1-2 on average), so this algorithmic rate can exceed the machine's peak; what the kernel is bound by is "
-                        "VALU issue of the shading arithmetic (valu_issue_busy, from the PMC profile).",
-            },
+            "roofline": roof,
         }
-        if st["bvh_node_fetches"] > 0:
-            # LBVH traversal: the dominant cost is fetching node and triangle records (64 B each, once per wave);
-            # they come from L2 / Infinity Cache, priced here against the HBM peak as the outermost bound
-            fetched = (st["bvh_node_fetches"] * 64 + st["bvh_triangle_fetches"] * 64) / max(1, st["dispatches"])
-            gbs = fetched / (kernel_ms * 1e-3) * 1e-9
-            out["config"]["workload"] = out["config"]["workload"].replace("closest hit through the direction grid (PT_ACCEL_AUTO)", "device LBVH, wave-coherent traversal")
-            out["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": None,
-                               "kernel": "pt_render_kernel<bvh>", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": fetched,
-                               "brute_force_equivalent_TFLOP_per_s": achieved,
-                               "note": "bytes = (node records + triangle records) x 64, counted in-kernel once per wave fetch; "
-                                       "latency-bound pointer chasing served by L2/Infinity Cache, far below the HBM roof"}
         if large:
             out["large_scene"] = large
-        # HBM bytes per launch from rocprofv3 PMC passes of this same workload (profiles/r01_pmc_cornell_grid_v6.json:
-        # FETCH_SIZE 20762 KB doubled as the gfx950 correction prescribes, plus WRITE_SIZE 158514 KB, of which 33 MB are
-        # the image and the rest the parked samples of split tiles); counters cannot be read from inside this run
-        if args.workload == "cornell" and (W, H, spp) == (1920, 1080, 256):
-            out["roofline"]["traffic"] = 2 * 20762.0 * 1024 + 158514.03 * 1024
-            out["roofline"]["valu_issue_busy"] = 0.74
-            out["roofline"]["hbm_GB_per_s"] = out["roofline"]["traffic"] / (kernel_ms * 1e-3) * 1e-9   # against the 8000 GB/s peak: the path is not HBM-bound
-            out["roofline"]["hbm_frac"] = out["roofline"]["hbm_GB_per_s"] / 8000.0
+        if materials:
+            out["materials_mode"] = {"cornell": materials, "large_scene": materials_large}
         # the reference shader itself on Mesa llvmpipe, same scene, camera and passes: recorded in the build container (the
         # shader text does not travel to the GPU box), see oracle/time_c1.py --c2
-        gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "c2_cornell_1080p.json")
-        if args.workload == "cornell" and (W, H, spp) == (1920, 1080, 256) and os.path.exists(gold):
+        gold = os.path.join(ROOT, "tests", "golden", "c2_cornell_1080p.json")
+        if args.workload == "cornell" and args.shading == "reference" and (W, H, spp) == (1920, 1080, 256) and os.path.exists(gold):
             lp = json.load(open(gold))["llvmpipe"]
             out["llvmpipe_recorded"] = {"Mrays_per_s": lp["Mrays_per_s"], "ms_per_pass_median": lp["pass_ms_median"], "cores": lp["threads"],
                                         "renderer": lp["renderer"], "note": "reference pathtracing.fs, passes 1..256 of this workload, timed around glDrawArrays..glFinish "
                                         "in the build container, not on this machine; its final image is bit-identical to this run's (tests/golden/c2_cornell_1080p.json)"}
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene, spp)
+            out["cpu_baseline"] = cpu_baseline(scene, spp, args.shading)
         print(json.dumps(out), flush=True)
 
     tracer.close()
     if world > 1:
-        dist.barrier()   # rank 0 reports (CPU baseline, large scene) after the timed region: the ranks leave together
+        dist.barrier()   # rank 0 reports after the timed region: the ranks leave together
         dist.destroy_process_group()
 
 

@@ -111,8 +111,15 @@ typedef struct PtStats {
                                   that did useful work (paths in one wave end at different times) */
     uint64_t bvh_node_fetches; /* LBVH traversal: 64-byte node records fetched, counted once per WAVE (the walk is per wave) */
     uint64_t bvh_triangle_fetches; /* LBVH traversal: 64-byte triangle records (+4-byte id) fetched, once per wave */
-    uint64_t grid_triangle_tests; /* direction grid: triangle tests, counted per ray */
+    uint64_t grid_triangle_tests; /* direction grid: triangle tests, counted per ray; per-lane hierarchy walk (PT_SHADE_MATERIALS):
+                                  node and triangle records a lane fetched */
     uint64_t grid_entries;     /* direction grid as currently built: (cell, triangle) entries over all cells (0 = not built) */
+    uint64_t shaded_hits;      /* Shade() evaluations (pathtracing.fs:224): one per closest-hit query that hit, reused camera-ray
+                                  hits included */
+    uint64_t loop_triangle_visits; /* all-triangles loop: triangle records visited, counted once per WAVE and loop trip (every lane
+                                  of the wave tests its ray against each) */
+    uint64_t loop_full_tests;  /* all-triangles loop, measurement builds (-DPT_V_COUNT_FULL) only: of those visits, the ones that
+                                  went past the wave-uniform back-face skip; 0 in the product build */
     uint32_t dispatches;       /* pt_dispatch calls */
     float last_dispatch_ms;    /* device time of the most recent pt_dispatch (scheduler, render and fold kernels);
                                   0 unless timing is enabled */

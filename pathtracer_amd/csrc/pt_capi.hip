@@ -1322,10 +1322,10 @@ PtStatus pt_get_stats(PtContext* ctx, PtStats* out) {
     PT_REQUIRE(slots != nullptr, PT_ERR_HIP, "out of host memory");
     hipError_t ce = hipMemcpyAsync(slots, ctx->d_counters, kCounterBytes, hipMemcpyDeviceToHost, ctx->stream);
     if (ce == hipSuccess) ce = hipStreamSynchronize(ctx->stream);
-    unsigned long long c[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (ce == hipSuccess)
         for (size_t k = 0; k < PT_COUNTER_SLOTS; ++k)
-            for (int j = 0; j < 6; ++j) c[j] += slots[k * PT_COUNTER_STRIDE + j];
+            for (int j = 0; j < 9; ++j) c[j] += slots[k * PT_COUNTER_STRIDE + j];
     delete[] slots;
     PT_HIP_TRY(ce);
     out->rays = c[0];
@@ -1336,6 +1336,9 @@ PtStatus pt_get_stats(PtContext* ctx, PtStats* out) {
     out->bvh_triangle_fetches = c[3];
     out->grid_triangle_tests = c[5];
     out->grid_entries = ctx->grid_built ? ctx->grid_entries : 0;
+    out->shaded_hits = c[6];
+    out->loop_triangle_visits = c[7];
+    out->loop_full_tests = c[8];
     out->dispatches = ctx->dispatches;
     out->last_dispatch_ms = ctx->last_ms;
     out->total_dispatch_ms = ctx->total_ms;

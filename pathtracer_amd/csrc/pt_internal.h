@@ -167,7 +167,9 @@ struct PtKernelParams {
     const float* src;                   // RGBA32F image read (previous result)
     float* dst;                         // RGBA32F image written
     unsigned long long* counters;       // PT_COUNTER_SLOTS x PT_COUNTER_STRIDE: per slot [0] rays, [1] lane slots spent (wave loop trips x 64),
-                                        // [2] node records, [3] triangle records fetched by the hierarchy walk, [4] queries actually evaluated
+                                        // [2] node records, [3] triangle records fetched by the hierarchy walk, [4] queries actually evaluated,
+                                        // [5] per-lane triangle tests / walk steps, [6] hits shaded, [7] records visited and [8] tests past the
+                                        // back-face skip by the all-triangles loop (both per wave)
     const PtWorkItem* items;            // work list (block -> item), or null = block b renders tile b with all samples
     const uint32_t* sched_counts;       // [0] number of items, [1] number of split tiles (device scalars written by the scheduler)
     const uint32_t* split_tiles;        // scratch slot -> tile

@@ -157,8 +157,10 @@ struct Hit {
 // (see pt_internal.h). The record registers are wave-uniform (scalar).
 struct TriRec { float4 a, b, c, d; };  // e1.xyz e2.x | e2.yz ap.xy | ap.z r.xyz | e2r - - -
 
+// `full` counts the tests that went past the wave-uniform back-face skip -- only in builds with -DPT_V_COUNT_FULL
+// (a measurement variant: the add costs a vector instruction per test); otherwise it stays 0.
 template <bool ANY_ORDER>
-__device__ __forceinline__ void test_triangle(const TriRec& t, int id, v3 rd, Hit& h) {
+__device__ __forceinline__ void test_triangle(const TriRec& t, int id, v3 rd, Hit& h, unsigned& full) {
     const v3 e1 = V(t.a.x, t.a.y, t.a.z);
     const v3 e2 = V(t.a.w, t.b.x, t.b.y);
 #ifdef PT_V_VFIRST
@@ -176,6 +178,9 @@ __device__ __forceinline__ void test_triangle(const TriRec& t, int id, v3 rd, Hi
 #else
     if (!__builtin_amdgcn_ballot_w64(det >= 0.0001f)) return;
 #endif
+#endif
+#ifdef PT_V_COUNT_FULL
+    ++full;
 #endif
     const v3 ap = V(t.b.z, t.b.w, t.c.x);
     const float u = dot3(ap, q);
@@ -203,13 +208,16 @@ __device__ __forceinline__ void test_triangle(const TriRec& t, int id, v3 rd, Hi
 // shader's commented line fs:274 does): fs:136-168 as written, from a record that holds a, e1, e2 and the triangle's
 // material id:  a.xyz e1.x | e1.yz e2.xy | e2.z matid - - | -
 template <bool ANY_ORDER>
-__device__ __forceinline__ void test_triangle_from(const TriRec& t, int id, v3 ro, v3 rd, Hit& h) {
+__device__ __forceinline__ void test_triangle_from(const TriRec& t, int id, v3 ro, v3 rd, Hit& h, unsigned& full) {
     const v3 a = V(t.a.x, t.a.y, t.a.z);
     const v3 e1 = V(t.a.w, t.b.x, t.b.y);
     const v3 e2 = V(t.b.z, t.b.w, t.c.x);
     const v3 q = cross3(rd, e2);
     const float det = dot3(e1, q);
     if (!__builtin_amdgcn_ballot_w64(det >= 0.0001f)) return;
+#ifdef PT_V_COUNT_FULL
+    ++full;
+#endif
     const v3 ap = ro - a;
     const v3 r = cross3(ap, e1);
     const float u = dot3(ap, q);
@@ -251,7 +259,7 @@ __device__ __forceinline__ TriRec load_rec(const float4* __restrict__ recs, int 
 // so records arrive through scalar loads; they are requested two triangles ahead of their use (two register sets,
 // alternating), which keeps the scalar-load latency off the wave's critical path. The buffer is padded with
 // PT_TRI_PAD all-zero records (det = 0 fails the cull), so the loop needs no remainder handling.
-__device__ __forceinline__ Hit intersect_mesh(const float* __restrict__ tris, int n, v3 rd) {
+__device__ __forceinline__ Hit intersect_mesh(const float* __restrict__ tris, int n, v3 rd, unsigned& full) {
     Hit h;
     h.t = 1.0e38f; h.id = -1; h.u = 0.f; h.v = 0.f; h.ood = 0.f;
     const float4* __restrict__ recs = reinterpret_cast<const float4*>(tris);
@@ -259,17 +267,17 @@ __device__ __forceinline__ Hit intersect_mesh(const float* __restrict__ tris, in
     // pt_compact_triangles_kernel), which keeps the ascending order the strict '<' relies on
     auto id_of = [](const TriRec& t) { return (int)__float_as_uint(t.d.w); };
 #ifdef PT_V_SIMPLE
-    for (int i = 0; i < n; ++i) { const TriRec t = load_rec(recs, i); test_triangle<false>(t, id_of(t), rd, h); }
+    for (int i = 0; i < n; ++i) { const TriRec t = load_rec(recs, i); test_triangle<false>(t, id_of(t), rd, h, full); }
 #else
     TriRec a0 = load_rec(recs, 0), a1 = load_rec(recs, 1);
     for (int i = 0; i < n; i += 4) {
         const TriRec b0 = load_rec(recs, i + 2), b1 = load_rec(recs, i + 3);
-        test_triangle<false>(a0, id_of(a0), rd, h);
-        test_triangle<false>(a1, id_of(a1), rd, h);
+        test_triangle<false>(a0, id_of(a0), rd, h, full);
+        test_triangle<false>(a1, id_of(a1), rd, h, full);
         a0 = load_rec(recs, i + 4);
         a1 = load_rec(recs, i + 5);
-        test_triangle<false>(b0, id_of(b0), rd, h);
-        test_triangle<false>(b1, id_of(b1), rd, h);
+        test_triangle<false>(b0, id_of(b0), rd, h, full);
+        test_triangle<false>(b1, id_of(b1), rd, h, full);
     }
 #endif
     return h;
@@ -281,19 +289,19 @@ __device__ __forceinline__ int live_triangles(const PtKernelParams& p) {
 }
 
 // fs:125-174 for rays with their own origins: same double-buffered scalar record stream.
-__device__ __forceinline__ Hit intersect_mesh_from(const float* __restrict__ tris_abs, int n, v3 ro, v3 rd) {
+__device__ __forceinline__ Hit intersect_mesh_from(const float* __restrict__ tris_abs, int n, v3 ro, v3 rd, unsigned& full) {
     Hit h;
     h.t = 1.0e38f; h.id = -1; h.u = 0.f; h.v = 0.f; h.ood = 0.f;
     const float4* __restrict__ recs = reinterpret_cast<const float4*>(tris_abs);
     TriRec a0 = load_rec(recs, 0), a1 = load_rec(recs, 1);
     for (int i = 0; i < n; i += 4) {
         const TriRec b0 = load_rec(recs, i + 2), b1 = load_rec(recs, i + 3);
-        test_triangle_from<false>(a0, i, ro, rd, h);
-        test_triangle_from<false>(a1, i + 1, ro, rd, h);
+        test_triangle_from<false>(a0, i, ro, rd, h, full);
+        test_triangle_from<false>(a1, i + 1, ro, rd, h, full);
         a0 = load_rec(recs, i + 4);
         a1 = load_rec(recs, i + 5);
-        test_triangle_from<false>(b0, i + 2, ro, rd, h);
-        test_triangle_from<false>(b1, i + 3, ro, rd, h);
+        test_triangle_from<false>(b0, i + 2, ro, rd, h, full);
+        test_triangle_from<false>(b1, i + 3, ro, rd, h, full);
     }
     return h;
 }
@@ -344,6 +352,7 @@ __device__ __forceinline__ CullRec load_cull(const float4* __restrict__ cull, in
 __device__ __forceinline__ Hit intersect_mesh_culled(const PtKernelParams& p, v3 rd, bool active, const CullRec& first, unsigned& tri_tests) {
     Hit h;
     h.t = 1.0e38f; h.id = -1; h.u = 0.f; h.v = 0.f; h.ood = 0.f;
+    unsigned full = 0;
     const float w = active ? 1.0f : 0.0f;
     v3 axis = V(wave_reduce<false>(rd.x * w), wave_reduce<false>(rd.y * w), wave_reduce<false>(rd.z * w));
     const float len2 = dot3(axis, axis);
@@ -375,7 +384,7 @@ __device__ __forceinline__ Hit intersect_mesh_culled(const PtKernelParams& p, v3
             while (true) {
                 const int inext = mask ? base + __builtin_ctzll(mask) : i;
                 const TriRec nxt = load_rec(recs, inext);  // requested before the current one is tested
-                test_triangle<false>(cur, i, rd, h);
+                test_triangle<false>(cur, i, rd, h, full);
                 if (!mask) break;
                 mask &= mask - 1;
                 cur = nxt;
@@ -399,6 +408,7 @@ __device__ __forceinline__ Hit intersect_bvh(const PtKernelParams& p, v3 ro, v3 
                                              unsigned& tri_tests) {
     Hit h;
     h.t = 1.0e38f; h.id = -1; h.u = 0.f; h.v = 0.f; h.ood = 0.f;
+    unsigned full = 0;
     // Reciprocal direction for the slab tests only (culling arithmetic is not part of the reference's numerics; it
     // only has to be conservative, which the padded boxes and the slack on `limit` guarantee). A zero component is
     // replaced by a tiny one of the same sign: the slab test then degenerates to "origin inside the slab".
@@ -421,15 +431,15 @@ __device__ __forceinline__ Hit intersect_bvh(const PtKernelParams& p, v3 ro, v3 
             const TriRec r0 = load_rec(recs, first), r1 = load_rec(recs, first + 1), r2 = load_rec(recs, first + 2),
                          r3 = load_rec(recs, first + 3);
             if (MOVING) {
-                test_triangle_from<true>(r0, (int)__float_as_uint(r0.d.w), ro, rd, h);
-                if (count > 1) test_triangle_from<true>(r1, (int)__float_as_uint(r1.d.w), ro, rd, h);
-                if (count > 2) test_triangle_from<true>(r2, (int)__float_as_uint(r2.d.w), ro, rd, h);
-                if (count > 3) test_triangle_from<true>(r3, (int)__float_as_uint(r3.d.w), ro, rd, h);
+                test_triangle_from<true>(r0, (int)__float_as_uint(r0.d.w), ro, rd, h, full);
+                if (count > 1) test_triangle_from<true>(r1, (int)__float_as_uint(r1.d.w), ro, rd, h, full);
+                if (count > 2) test_triangle_from<true>(r2, (int)__float_as_uint(r2.d.w), ro, rd, h, full);
+                if (count > 3) test_triangle_from<true>(r3, (int)__float_as_uint(r3.d.w), ro, rd, h, full);
             } else {
-                test_triangle<true>(r0, (int)__float_as_uint(r0.d.w), rd, h);
-                if (count > 1) test_triangle<true>(r1, (int)__float_as_uint(r1.d.w), rd, h);
-                if (count > 2) test_triangle<true>(r2, (int)__float_as_uint(r2.d.w), rd, h);
-                if (count > 3) test_triangle<true>(r3, (int)__float_as_uint(r3.d.w), rd, h);
+                test_triangle<true>(r0, (int)__float_as_uint(r0.d.w), rd, h, full);
+                if (count > 1) test_triangle<true>(r1, (int)__float_as_uint(r1.d.w), rd, h, full);
+                if (count > 2) test_triangle<true>(r2, (int)__float_as_uint(r2.d.w), rd, h, full);
+                if (count > 3) test_triangle<true>(r3, (int)__float_as_uint(r3.d.w), rd, h, full);
             }
             tri_tests += (unsigned)count;
         } else {
@@ -814,6 +824,8 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
     unsigned trips = 0;   // queries evaluated by the WAVE: trips x 64 lane slots were spent for `traced` useful ones
     unsigned node_visits = 0, tri_tests = 0;  // per WAVE (the BVH walk is wave-uniform): records fetched
     unsigned lane_tests = 0;                  // per LANE (direction grid): triangles tested
+    unsigned loop_full = 0;                   // per WAVE (all-triangles loop): tests that went past the wave-uniform back-face skip
+    unsigned shaded = 0;                      // per LANE: hits shaded
 
     CullRec cull0;
     if (KIND == 3) cull0 = load_cull(reinterpret_cast<const float4*>(p.cull), threadIdx.x & 63, p.num_triangles);
@@ -827,7 +839,7 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
             h = intersect_mesh_culled(p, d, want, cull0, tri_tests);
         } else if (want) {
             if (KIND == 0) h = intersect_world(p.spheres, o, d, n);
-            else if (KIND == 1) h = MATERIALS ? intersect_mesh_from(p.tris_abs, p.num_triangles, o, d) : intersect_mesh(p.tris, live_triangles(p), d);
+            else if (KIND == 1) h = MATERIALS ? intersect_mesh_from(p.tris_abs, p.num_triangles, o, d, loop_full) : intersect_mesh(p.tris, live_triangles(p), d, loop_full);
             else if (KIND == 2) h = intersect_bvh<MATERIALS>(p, o, d, s_stack[threadIdx.x >> 6], node_visits, tri_tests);
             else if (KIND == 5) {
                 bool overflow;
@@ -926,6 +938,7 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
             done = true;
         } else if (live && pending) {
             if (pend_hit) {
+                ++shaded;
                 if (MATERIALS) {
                     const v3 P = ro + rd * pend_t;  // recPoint, fs:163
                     shade_materials(rng, p.materials, p.material_ids[pend_id], energy, emitted, ro, rd, P, pend_n);
@@ -977,6 +990,7 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
     }
     const unsigned long long wave_rays = wave_sum(rays), wave_traced = wave_sum(traced);
     const unsigned long long wave_tests = (KIND == 4 || KIND == 5) ? wave_sum(lane_tests) : 0ull;
+    const unsigned long long wave_shaded = wave_sum(shaded);
     const unsigned wave_trips = __builtin_amdgcn_readfirstlane(__reduce_max_trips(trips));
     if ((threadIdx.x & 63) == 0 && wave_rays) {
         unsigned long long* counters = p.counters + (size_t)(blockIdx.x % PT_COUNTER_SLOTS) * PT_COUNTER_STRIDE;
@@ -996,6 +1010,12 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
             atomicAdd(&counters[3], (unsigned long long)__builtin_amdgcn_readfirstlane(tri_tests));
         }
         if (KIND == 4 || KIND == 5) atomicAdd(&counters[5], wave_tests);
+        if (wave_shaded) atomicAdd(&counters[6], wave_shaded);
+        if (KIND == 1) {  // the loop visits every (live) record once per trip of the wave
+            const unsigned n = MATERIALS ? (unsigned)p.num_triangles : (unsigned)live_triangles(p);
+            atomicAdd(&counters[7], (unsigned long long)wave_trips * n);
+            atomicAdd(&counters[8], (unsigned long long)__builtin_amdgcn_readfirstlane(loop_full));
+        }
     }
 }
 
@@ -1011,8 +1031,8 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_primary_kernel(const PtKer
     Hit h;
     v3 N;
     if (KIND == 0) h = intersect_world(p.spheres, ro, rd, N);
-    else if (KIND == 1) h = intersect_mesh(p.tris, live_triangles(p), rd);
     unsigned nv = 0, tt = 0;
+    if (KIND == 1) h = intersect_mesh(p.tris, live_triangles(p), rd, tt);
     if (KIND == 2) h = intersect_bvh<false>(p, ro, rd, s_stack[threadIdx.x >> 6], nv, tt);
     if (KIND == 3) h = intersect_mesh_culled(p, rd, in_window, load_cull(reinterpret_cast<const float4*>(p.cull), threadIdx.x & 63, p.num_triangles), tt);
     if (KIND == 4) h = intersect_grid(p, rd, tt, N);

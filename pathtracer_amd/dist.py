@@ -8,7 +8,8 @@ index, so the work shards two ways with no exchange until the end:
                  running fp32 SUM; one all-reduce(sum) of the image merges them and a scale by 1/N gives the mean.
                  Differs from the sequential running mean only by fp32 rounding.
   tile split     rank r owns a set of rows (interleaved blocks, for balance) and runs ALL samples for them with the
-                 reference recurrence, so its pixels are bit-identical to a 1-GPU render; the merge moves bytes only.
+                 reference recurrence, so its pixels are bit-identical to a 1-GPU render; the merge is an all-gather of
+                 the owned rows (bytes only, no arithmetic), which can run beside the rendering of the next frame.
 
 The renderer is injected (`render_sum(first, stride, count)` / `render_rows(y0, h)`), so this module holds no
 tracing code: on the GPU box the callables wrap pathtracer_amd.Tracer, in CPU tests they wrap a checker.
@@ -104,10 +105,76 @@ class OverlappedSampleMerge:
         return self.merged
 
 
-def merge_tile_split(image, height, block=16, group=None):
-    """Every rank ends up with the full image: rows it does not own are zero before the call, so a sum all-reduce
-    moves each row from its owner to everyone without changing a bit (x + 0 + ... + 0 is exact)."""
-    _all_reduce_sum(image, group)
+class TileGather:
+    """Tile-split merge: every rank sends the rows it owns and receives everyone else's -- an all-gather, half the bytes
+    of a sum all-reduce over the zero-padded image and no arithmetic, so owned pixels arrive bit for bit.
+
+    Rank r owns the row blocks r, r + R, ... (`row_blocks`). Its rows are packed into one contiguous send buffer, padded
+    to the largest per-rank row count (heights that are not a multiple of block x world give ranks different counts), all
+    buffers are gathered with one `all_gather_into_tensor`, and the valid rows are scattered to their places in the merged
+    image. `submit(image)` packs and starts the exchange without waiting (RCCL runs it on its own stream, ordered after
+    the pack), so the caller may clear `image` and render the next frame at once; `finish()` waits for the exchange in
+    flight and returns the merged image; `submit` calls it first, so one set of buffers is enough. With
+    `overlapped=False`, or over a backend that cannot gather device memory (gloo rehearsals on a GPU stage through the
+    host), `submit` completes the exchange itself. Call both under the stream the renderer uses."""
+
+    def __init__(self, like, rank, world, block=16, group=None, overlapped=True):
+        H = like.shape[0]
+        rows = [torch.tensor([y for y0, h in row_blocks(r, world, H, block) for y in range(y0, y0 + h)], dtype=torch.long) for r in range(world)]
+        self.max_rows = max(1, max(len(r) for r in rows))
+        self.my_rows = rows[rank].to(like.device)
+        self.n_mine = len(rows[rank])
+        # position in the gathered buffer -> image row, for every valid (non-padding) row
+        self.src = torch.cat([torch.arange(len(r), dtype=torch.long) + k * self.max_rows for k, r in enumerate(rows)]).to(like.device)
+        self.dst = torch.cat(rows).to(like.device)
+        self.send = torch.zeros((self.max_rows,) + tuple(like.shape[1:]), dtype=like.dtype, device=like.device)
+        self.recv = torch.zeros((world * self.max_rows,) + tuple(like.shape[1:]), dtype=like.dtype, device=like.device)
+        self.merged = torch.empty_like(like)
+        self.group = group
+        self.world = world
+        self.work = None
+        self.pending = False
+        on = dist.is_available() and dist.is_initialized() and world > 1
+        self.direct = on and (not like.is_cuda or dist.get_backend(group) == "nccl")
+        self.staged = on and not self.direct
+        self.asynchronous = bool(overlapped and self.direct)
+        self.bytes_sent_per_rank = self.send.numel() * self.send.element_size() * max(0, world - 1)
+
+    def submit(self, image):
+        self.finish()
+        if self.n_mine:
+            torch.index_select(image, 0, self.my_rows, out=self.send[:self.n_mine])
+        self.pending = True
+        if self.world <= 1 or not (self.direct or self.staged):
+            self.recv[:self.max_rows].copy_(self.send)
+        elif self.staged:
+            host_send, host_recv = self.send.cpu(), torch.empty(self.recv.shape, dtype=self.recv.dtype)
+            dist.all_gather_into_tensor(host_recv, host_send, group=self.group)
+            self.recv.copy_(host_recv)
+        else:
+            self.work = dist.all_gather_into_tensor(self.recv, self.send, group=self.group, async_op=self.asynchronous)
+        if not self.asynchronous:
+            self.finish()
+
+    def finish(self):
+        if self.work is not None:
+            self.work.wait()  # the current stream waits for the exchange; the host does not
+            self.work = None
+        if self.pending:
+            self.merged.index_copy_(0, self.dst, self.recv.index_select(0, self.src))
+            self.pending = False
+        return self.merged
+
+
+def merge_tile_split(image, height=None, block=16, group=None, rank=None, world=None):
+    """One-shot form of TileGather: every rank ends up with the full image (in place). Rows a rank does not own are
+    overwritten with their owner's; what they held before does not matter."""
+    on = dist.is_available() and dist.is_initialized()
+    rank = (dist.get_rank(group) if on else 0) if rank is None else rank
+    world = (dist.get_world_size(group) if on else 1) if world is None else world
+    g = TileGather(image, rank, world, block, group, overlapped=False)
+    g.submit(image)
+    image.copy_(g.finish())
     return image
 
 
