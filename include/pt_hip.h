@@ -261,6 +261,15 @@ PtStatus pt_readback_primary(PtContext* ctx, int32_t* ids, float* t);
 PtStatus pt_enable_timing(PtContext* ctx, int32_t enabled);
 PtStatus pt_get_stats(PtContext* ctx, PtStats* out);
 PtStatus pt_reset_stats(PtContext* ctx);
+/* No counterpart in the reference (its shader only has the loop). Self-check of the search structure the current modes
+ * select for a dispatch -- direction grid, LBVH (per-wave or per-lane walk), or the loop's compacted record array: every
+ * camera ray of the window, and `bounces` generations of the rays Shade() makes of the hits (sample index 1), are answered by
+ * that structure AND by the shader's own search, the loop over every uploaded triangle in index order (pathtracing.fs:129-168),
+ * on the device. result[0] = queries compared, [1] = queries whose closest triangle differs, [2] = queries whose hit distance
+ * differs in any bit. [1] and [2] are 0 when the structure is exact, which is what keeps images identical to the shader's.
+ * Costs one all-triangles search per query: seconds for a 4K frame over a million triangles. PT_ERR_STATE when the modes
+ * select no structure (plain loop), PT_ERR_UNSUPPORTED for PT_ACCEL_CULL. */
+PtStatus pt_verify_accel(PtContext* ctx, int32_t bounces, uint64_t result[3]);
 /* No counterpart in the reference. The kernels form 1/x, sqrt(x) and the quotient inside their log2 with shorter
  * instruction sequences than the compiler's IEEE division and square root; the results are required to be the same bit
  * for bit (that is what keeps images identical to the shader's on llvmpipe). This runs every one of the 2^32 float

@@ -240,14 +240,30 @@ def config4_cases():
             ("torus_distorted_4k_crop", both, ref_cam(3840, 2160), 3840, 2160, po.VARIANT_MESH, geo, [1, 4], (2585, 200, 64, 64))]
 
 
+def tiny_materials_case():
+    """The diffuse/emissive mode on the Cornell box with albedos of 1e-13..1e-15 and an emitter of 1e-12: throughputs reach
+    1e-39 after three bounces, so products, sky terms, emitted radiance and the running mean all pass through the denormal
+    range. Pins how the reference's GL implementation treats denormals (flushed to zero, inputs and results) in every
+    operation of the path, including the `energy == 0` path end that a flushed throughput triggers."""
+    d, _ = run_obj_dump("cornell_box")
+    sph, _ = po.reference_spheres_and_materials()
+    cv, ci = po.mesh_from_obj_arrays(d["v"], d["idx_v"], None, translation=(0, 0, 0))
+    tab = np.array([[4e-13, 3e-13, 2e-13, 0], [1e-13, 2e-14, 3e-15, 0], [2e-14, 1e-13, 3e-14, 0], [3e-15, 5e-14, 1e-13, 0],
+                    [1.0, 0.9, 0.8, 1e-12], [5e-14, 5e-14, 5e-14, 0]], np.float32)   # white red green blue light, no-material
+    ids = np.where(d["mat_ids"] < 0, len(tab) - 1, d["mat_ids"])
+    scene = po.Scene(cv, ci, sph, tab, ids)
+    cam = po.camera(39.3, 96, 96, (278, 273, -800), (278, 273, 0), (0, 1, 0))
+    return ("cornell_materials_tiny_96", scene, cam, 96, 96, po.VARIANT_MESH, po.NORMALS_GEOMETRIC, [1, 2, 8], None)
+
+
 def only(names):
     """Generates the named cases and leaves every other fixture as it is (python3 oracle/gen_golden.py --only a,b)."""
     path = f"{GOLD}/generation_report.json"
     report = json.load(open(path)) if os.path.exists(path) else []
-    for (name, sc, cam, W, H, variant, nm, spp, crop) in config4_cases():
+    for (name, sc, cam, W, H, variant, nm, spp, crop) in config4_cases() + [tiny_materials_case()]:
         if name not in names:
             continue
-        fx, rep = render_case(name, sc, cam, W, H, variant, nm, spp, crop)
+        fx, rep = render_case(name, sc, cam, W, H, variant, nm, spp, crop, shading_mode=1 if "materials" in name else 0)
         np.savez_compressed(f"{GOLD}/case_{name}.npz", **fx)
         report = [r for r in report if r.get("case") != name] + [rep]
     json.dump(report, open(path, "w"), indent=1)
@@ -322,8 +338,8 @@ def main():
         np.savez_compressed(f"{GOLD}/case_{name}.npz", **fx)
         report.append(rep)
 
-    for (name, sc, cam, W, H, variant, nm, spp, crop) in config4_cases():
-        fx, rep = render_case(name, sc, cam, W, H, variant, nm, spp, crop)
+    for (name, sc, cam, W, H, variant, nm, spp, crop) in config4_cases() + [tiny_materials_case()]:
+        fx, rep = render_case(name, sc, cam, W, H, variant, nm, spp, crop, shading_mode=1 if "materials" in name else 0)
         np.savez_compressed(f"{GOLD}/case_{name}.npz", **fx)
         report.append(rep)
 

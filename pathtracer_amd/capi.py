@@ -77,6 +77,7 @@ SIGNATURES = {
     "pt_enable_timing": (C.c_int, [C.c_void_p, C.c_int32]),
     "pt_get_stats": (C.c_int, [C.c_void_p, C.POINTER(PtStats)]),
     "pt_reset_stats": (C.c_int, [C.c_void_p]),
+    "pt_verify_accel": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64)]),
     "pt_selftest_arithmetic": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
 }
 
@@ -264,6 +265,12 @@ class Tracer:
 
     def reset_stats(self):
         check(self._lib.pt_reset_stats(self._ctx), self._lib)
+
+    def verify_accel(self, bounces=1):
+        """(queries compared, ids differing, distances differing) of the selected search structure against the all-triangles loop."""
+        out = (C.c_uint64 * 3)()
+        check(self._lib.pt_verify_accel(self._ctx, bounces, out), self._lib)
+        return tuple(int(v) for v in out)
 
     def selftest_arithmetic(self):
         """(reciprocal, square root, log2 quotient): inputs for which the kernels' short sequences differ from IEEE; all 0."""

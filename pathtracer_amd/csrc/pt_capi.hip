@@ -1360,6 +1360,41 @@ PtStatus pt_reset_stats(PtContext* ctx) {
     return PT_OK;
 }
 
+PtStatus pt_verify_accel(PtContext* ctx, int32_t bounces, uint64_t result[3]) {
+    PtStatus s = bind(ctx);
+    if (s != PT_OK) return s;
+    PT_REQUIRE(result != nullptr, PT_ERR_INVALID_ARGUMENT, "result is null");
+    PT_REQUIRE(bounces >= 0 && bounces <= 64, PT_ERR_INVALID_ARGUMENT, "bounces must be in [0, 64]; got %d", bounces);
+    result[0] = result[1] = result[2] = 0;
+    PtKernelParams p;
+    const Program* prog = nullptr;
+    s = fill_params(ctx, &p, &prog);
+    if (s != PT_OK) return s;
+    PT_REQUIRE(prog->kind == PT_PROGRAM_MESH, PT_ERR_STATE, "pt_verify_accel checks the mesh search structures; the program in use traces spheres");
+    PT_REQUIRE(p.num_triangles > 0, PT_ERR_STATE, "u_NumTriangles is 0: nothing to check");
+    PT_REQUIRE(!p.cull, PT_ERR_UNSUPPORTED, "PT_ACCEL_CULL has no self-check");
+    const bool structure = p.shading_mode == (int32_t)PT_SHADE_MATERIALS ? p.bvh_nodes_abs != nullptr : (p.grid_cells || p.bvh_nodes || p.live_count);
+    PT_REQUIRE(structure, PT_ERR_STATE, "the current modes select the plain loop over all triangles: there is no search structure to check "
+               "(call pt_build_accel, or trace all uploaded triangles)");
+    p.first_sample = 1;
+    p.num_samples = 1;
+    p.sample_stride = 1;
+    p.verify_tris = ctx->d_tris;
+    p.verify_bounces = bounces;
+    unsigned long long* d = nullptr;
+    PT_HIP_TRY(hipMalloc(&d, 3 * sizeof(unsigned long long)));
+    p.verify_out = d;
+    hipError_t e = hipMemsetAsync(d, 0, 3 * sizeof(unsigned long long), ctx->stream);
+    if (e == hipSuccess) e = pt_launch_verify(p, ctx->stream);
+    unsigned long long h[3] = {0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    PT_HIP_TRY(e);
+    for (int k = 0; k < 3; ++k) result[k] = h[k];
+    return PT_OK;
+}
+
 PtStatus pt_selftest_arithmetic(PtContext* ctx, uint64_t mismatches[3]) {
     PtStatus s = bind(ctx);
     if (s != PT_OK) return s;

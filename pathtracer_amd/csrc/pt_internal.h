@@ -181,6 +181,9 @@ struct PtKernelParams {
     int32_t primary_cache_valid;        // 1: read it; 0: evaluate the camera ray and write it
     int32_t* out_ids;                   // primary pass only
     float* out_t;                       // primary pass only
+    const float* verify_tris;           // self-check only: the records of ALL triangles in index order (never compacted)
+    unsigned long long* verify_out;     // self-check only: [0] queries compared, [1] ids differing, [2] distances differing
+    int32_t verify_bounces;             // self-check only: generations of bounce rays compared after the camera rays
 };
 
 // Launchers (defined in pt_kernels.hip). All are asynchronous on `stream`.
@@ -204,3 +207,6 @@ hipError_t pt_launch_schedule_items(const uint32_t* tile_cost, PtWorkItem* items
                                     int num_tiles, int num_samples, int max_split_tiles, hipStream_t stream);
 #define PT_SCHED_TMP_WORDS (4 + 64 * 64)  // scratch of the scheduler's launches: total cost, per-workgroup bucket counts
 hipError_t pt_launch_primary(const PtKernelParams& p, int program_kind, hipStream_t stream);
+// every camera ray (and p.verify_bounces generations of bounce rays) through the structure `p` selects AND through the loop
+// over all of p.verify_tris; counts into p.verify_out. hipErrorInvalidValue when `p` selects no structure to check.
+hipError_t pt_launch_verify(const PtKernelParams& p, hipStream_t stream);

@@ -1041,6 +1041,64 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_primary_kernel(const PtKer
     if (p.out_t) p.out_t[pix] = h.t;
 }
 
+// Self-check of a search structure: every pixel's camera ray, and `verify_bounces` generations of the rays Shade() makes of
+// the hits (sample index first_sample), are answered twice -- by the shader's own search, the loop over EVERY triangle record
+// in index order (pathtracing.fs:129; not the compacted array), and by the structure a dispatch would use (KIND as in
+// pt_render_kernel; 1 = the compacted loop). verify_out: [0] queries compared, [1] queries whose triangle differs, [2] queries
+// whose distance differs in any bit. The path continues along the loop's answer.
+template <int KIND, bool MATERIALS>
+__global__ __launch_bounds__(PT_TILE_THREADS) void pt_verify_kernel(const PtKernelParams p) {
+    __shared__ uint32_t s_stack[(KIND == 2 || KIND == 5) ? PT_TILE_WAVES : 1][(KIND == 2 || KIND == 5) ? PT_BVH_STACK : 1];
+    __shared__ uint32_t s_lane_stack[KIND == 5 ? PT_TILE_WAVES : 1][KIND == 5 ? PT_LANE_STACK * 64 : 1];
+    int x, y;
+    bool live = pixel_of_lane(p, (int)blockIdx.x, x, y);
+    Rng rng;
+    rng.fcx = (float)x + 0.5f;
+    rng.fcy = (float)y + 0.5f;
+    rng.samples = (float)p.first_sample;
+    rng.sx = 0.0f;
+    v3 ro = V(p.ro[0], p.ro[1], p.ro[2]);
+    v3 rd = primary_direction(p, rng.fcx, rng.fcy);
+    v3 energy = V(1.0f, 1.0f, 1.0f), emitted = V(0.f, 0.f, 0.f);
+    unsigned compared = 0, bad_id = 0, bad_t = 0, unused = 0, nv = 0, tt = 0;
+    for (int g = 0; g <= p.verify_bounces; ++g) {
+        if (live) {
+            Hit a, b;
+            v3 gn = V(0.f, 0.f, 0.f);
+            a = MATERIALS ? intersect_mesh_from(p.tris_abs, p.num_triangles, ro, rd, unused) : intersect_mesh(p.verify_tris, p.num_triangles, rd, unused);
+            if (KIND == 1) b = intersect_mesh(p.tris, live_triangles(p), rd, unused);
+            else if (KIND == 2) b = intersect_bvh<MATERIALS>(p, ro, rd, s_stack[threadIdx.x >> 6], nv, tt);
+            else if (KIND == 5) {
+                bool overflow;
+                b = intersect_bvh_lanes(p, ro, rd, s_lane_stack[threadIdx.x >> 6], overflow, tt);
+                if (overflow) b = intersect_bvh<true>(p, ro, rd, s_stack[threadIdx.x >> 6], nv, tt);
+            } else b = intersect_grid(p, rd, tt, gn);
+            ++compared;
+            bad_id += a.id != b.id ? 1u : 0u;
+            bad_t += __float_as_uint(a.t) != __float_as_uint(b.t) ? 1u : 0u;
+            if (a.id < 0) {
+                live = false;
+            } else {
+                const v3 N = mesh_normal(p, a);
+                if (MATERIALS) {
+                    const v3 P = ro + rd * a.t;
+                    shade_materials(rng, p.materials, p.material_ids[a.id], energy, emitted, ro, rd, P, N);
+                    live = !(energy.x == 0.0f && energy.y == 0.0f && energy.z == 0.0f);
+                } else {
+                    shade(rng, energy.x, rd, N);
+                    live = energy.x != 0.0f;
+                }
+            }
+        }
+    }
+    const unsigned long long c = wave_sum(compared), bi = wave_sum(bad_id), bt = wave_sum(bad_t);
+    if ((threadIdx.x & 63) == 0 && c) {
+        atomicAdd(&p.verify_out[0], c);
+        if (bi) atomicAdd(&p.verify_out[1], bi);
+        if (bt) atomicAdd(&p.verify_out[2], bt);
+    }
+}
+
 // The short reciprocal, square-root and log2-quotient sequences against the compiler's IEEE division and square root, for
 // every float bit pattern: bad[0] reciprocal, bad[1] square root, bad[2] quotient -- inputs whose results differ in any
 // bit (NaN payloads included). All three must stay 0.
@@ -1458,6 +1516,20 @@ hipError_t pt_launch_render(const PtKernelParams& p, int program_kind, hipStream
     else hipLaunchKernelGGL((pt_render_kernel<1, false>), grid, block, 0, stream, p);
     if (p.items && p.max_split_tiles > 0 && p.num_samples > 1)
         hipLaunchKernelGGL(pt_fold_samples_kernel, dim3(p.max_split_tiles), dim3(PT_TILE_THREADS), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t pt_launch_verify(const PtKernelParams& p, hipStream_t stream) {
+    if (p.win_w <= 0 || p.win_h <= 0) return hipSuccess;
+    const dim3 grid(window_tiles(p)), block(PT_TILE_THREADS);
+    if (p.shading_mode == 1) {
+        if (p.bvh_nodes_abs && p.lane_walk) hipLaunchKernelGGL((pt_verify_kernel<5, true>), grid, block, 0, stream, p);
+        else if (p.bvh_nodes_abs) hipLaunchKernelGGL((pt_verify_kernel<2, true>), grid, block, 0, stream, p);
+        else return hipErrorInvalidValue;  // the materials mode without a hierarchy IS the all-triangles loop
+    }
+    else if (p.grid_cells) hipLaunchKernelGGL((pt_verify_kernel<4, false>), grid, block, 0, stream, p);
+    else if (p.bvh_nodes) hipLaunchKernelGGL((pt_verify_kernel<2, false>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((pt_verify_kernel<1, false>), grid, block, 0, stream, p);
     return hipGetLastError();
 }
 

@@ -9,6 +9,8 @@ CASES = ["monkey_mesh_128", "monkey_mesh_160x90", "monkey_mesh_1080p_crop", "wor
          "cornell_geo_128", "cornell_geo_1080p_crop", "suzanne_geo_96",
          # build-defined diffuse/emissive mode: llvmpipe ran the reference shader with oracle/llvmpipe/edits/mesh_materials_geo.txt
          "cornell_materials_128", "cornell_materials_1080p_crop",
+         # the same mode with albedos of 1e-13..1e-15: throughputs, sky terms and the running mean pass through the denormal range
+         "cornell_materials_tiny_96",
          # BASELINE configuration 4: the torus, and the torus next to its deterministically distorted copy
          "torus_geo_128", "torus_distorted_geo_128", "torus_distorted_geo_256x144", "torus_distorted_4k_crop"]
 

@@ -367,3 +367,78 @@ def test_direction_grid_when_the_queue_of_large_jobs_overflows(scene_kind):
             assert all(e > nt for e in entries)  # a grid was built (on a coarser resolution than the preferred one)
     finally:
         t.close()
+
+
+# ---- pt_verify_accel: the selected search structure against the shader's own all-triangles loop, on the device
+
+def _verify(t, accel, bounces):
+    t.set_accel_mode(accel)
+    compared, bad_id, bad_t = t.verify_accel(bounces)
+    t.set_accel_mode(0)
+    return compared, bad_id, bad_t
+
+
+@pytest.mark.parametrize("workload,size", [("cornell", (640, 360)), ("monkeyhead2", (640, 360)), ("suzanne", (480, 270)),
+                                           ("torus_distorted", (960, 540))])
+def test_self_check_of_every_structure(workload, size):
+    """Camera rays and three generations of bounce rays: direction grid, LBVH and the compacted loop give the triangle and
+    the distance the loop over all triangles gives, for every query."""
+    from pathtracer_amd import PtError, Tracer
+    from pathtracer_amd.scenes import SceneData
+    scene = SceneData(workload, *size)
+    with Tracer(0) as t:
+        scene.upload(t, accel=False)
+        t.target_create(scene.width, scene.height)
+        compared, bad_id, bad_t = _verify(t, 0, 3)          # no pt_build_accel yet: the loop over the compacted records
+        assert compared > scene.width * scene.height and (bad_id, bad_t) == (0, 0)
+        t.build_accel()
+        results = {accel: _verify(t, accel, 3) for accel in (2, 4)}
+        for accel, (c, bi, bt) in results.items():
+            assert c == compared and (bi, bt) == (0, 0), (accel, c, bi, bt)
+        assert _verify(t, 1, 1)[1:] == (0, 0)                # PT_ACCEL_BRUTE still walks the compacted records
+        t.set_uniforms(scene.camera, scene.num_triangles - 1, 10)   # a prefix of the mesh: the plain loop, nothing to check
+        with pytest.raises(PtError) as err:
+            t.verify_accel(1)
+        assert err.value.status == 3
+        t.set_uniforms(scene.camera, scene.num_triangles, 10)
+        # rays with their own origins (diffuse/emissive mode): per-lane and per-wave hierarchy walk
+        if workload != "cornell":                            # (36 triangles: AUTO keeps the loop there)
+            t.upload_materials(scene.material_table)
+            t.upload_material_ids(scene.material_ids)
+            t.set_shading_mode(1)
+            c, bi, bt = _verify(t, 2, 3)
+            assert c > scene.width * scene.height and (bi, bt) == (0, 0)
+
+
+def test_self_check_on_the_full_4k_million_triangle_frame():
+    """BASELINE configuration 5's frame: every camera ray of the 3840x2160 view of the 999,744-triangle scene and the first
+    generation of bounce rays, through the direction grid and through the LBVH, against the loop over all triangles."""
+    from pathtracer_amd import Tracer
+    from pathtracer_amd.scenes import SceneData
+    scene = SceneData("instanced")
+    with Tracer(0) as t:
+        scene.upload(t)
+        t.target_create(scene.width, scene.height)
+        c4, bi, bt = _verify(t, 4, 1)
+        assert c4 > scene.width * scene.height and (bi, bt) == (0, 0)
+        c2, bi, bt = _verify(t, 2, 0)
+        assert c2 == scene.width * scene.height and (bi, bt) == (0, 0)
+
+
+def test_self_check_reports_a_broken_structure():
+    """The check is not vacuous: a direction grid too coarse for its margins cannot happen by construction, so the test breaks
+    the comparison the other way round -- it traces fewer triangles than the structure holds, where the library itself refuses
+    the structure, and checks a moved camera gets a rebuilt grid (a stale one would show up here as mismatches)."""
+    import pt_oracle as po
+    from pathtracer_amd import Tracer
+    from pathtracer_amd.scenes import SceneData
+    scene = SceneData("monkeyhead2", 320, 180)
+    with Tracer(0) as t:
+        scene.upload(t)
+        t.target_create(320, 180)
+        assert _verify(t, 4, 2)[1:] == (0, 0)
+        for eye in ((0.4, 0.2, 0.5), (0.0, 0.0, 2.2), (-1.5, 0.3, 3.0)):     # beside, just in front of, and next to the mesh
+            t.set_uniforms(po.camera(60.0, 320, 180, eye, (0, 0, 3), (0, 1, 0)), scene.num_triangles, 10)
+            for accel in (0, 2, 4):
+                c, bi, bt = _verify(t, accel, 2)
+                assert c >= 320 * 180 and (bi, bt) == (0, 0), (eye, accel, c, bi, bt)
