@@ -80,12 +80,16 @@ typedef enum PtAccumMode {
 typedef enum PtShadingMode {
     PT_SHADE_REFERENCE = 0, /* the shader as committed: the fetched material is overwritten with 0.5 (pathtracing.fs:228-229),
                                every surface is the same modified-Phong lobe, the ray origin never moves */
-    PT_SHADE_MATERIALS = 1  /* build-defined: the fetched material (r,g,b,e) is kept. e > 0: emitter of radiance rgb*e, the
+    PT_SHADE_MATERIALS = 1, /* build-defined: the fetched material (r,g,b,e) is kept. e > 0: emitter of radiance rgb*e, the
                                path ends; otherwise Lambert of albedo rgb, cosine-weighted about the normal with the shader's
                                own GetTangentSpace/randomHemisphere (pathtracing.fs:44-76; the form of its commented lines
                                :269-279), origin moved to the hit point (:274), emitted radiance added next to the sky term
                                (:410). Mesh programs only. Its definition is the shader text with exactly these
                                statements edited in; the tests compare against that text run by a GLSL implementation. */
+    PT_SHADE_MATERIALS_UNIT = 2 /* PT_SHADE_MATERIALS with the Lambert bounce in the other form the reference carries as a commented
+                               line: rd = normalize(N + randomUnitVector()) (pathtracing.fs:272), randomUnitVector() as at
+                               pathtracing.fs:57-65 (z uniform in [-1, 1), then a point on the circle of that height). Everything
+                               else as PT_SHADE_MATERIALS. */
 } PtShadingMode;
 
 /* The program's uniforms (pathtracing.fs:6-9,17-18), set per frame at PathTracer.cpp:1372-1382.

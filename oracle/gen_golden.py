@@ -120,7 +120,7 @@ def render_case(name, scene, cam, W, H, variant, normal_mode, spp_list, crop=Non
     if shading_mode:
         assert variant == po.VARIANT_MESH and normal_mode == po.NORMALS_GEOMETRIC
         job.update(rad_base)
-        job["edits"] = f"{EDITS}/mesh_materials_geo.txt"
+        job["edits"] = f"{EDITS}/{'mesh_materials_unit_geo' if shading_mode == 2 else 'mesh_materials_geo'}.txt"
     if not crop:
         job["present_out"] = f"{tmp}/present.u8"   # the reference's copy.fs pass over the final image
     _, dumps, info = harness(job, tmp)
@@ -256,14 +256,30 @@ def tiny_materials_case():
     return ("cornell_materials_tiny_96", scene, cam, 96, 96, po.VARIANT_MESH, po.NORMALS_GEOMETRIC, [1, 2, 8], None)
 
 
+def unit_materials_case():
+    """The diffuse/emissive mode with the Lambert bounce of fs:272, rd = normalize(N + randomUnitVector()): Cornell box with
+    the table of cornell_box.mtl."""
+    d, _ = run_obj_dump("cornell_box")
+    sph, _ = po.reference_spheres_and_materials()
+    cv, ci = po.mesh_from_obj_arrays(d["v"], d["idx_v"], None, translation=(0, 0, 0))
+    tab = po.material_table_from_mtl(d["mat_values"])
+    scene = po.Scene(cv, ci, sph, tab, np.where(d["mat_ids"] < 0, len(tab) - 1, d["mat_ids"]))
+    cam = po.camera(39.3, 128, 128, (278, 273, -800), (278, 273, 0), (0, 1, 0))
+    return ("cornell_materials_unit_128", scene, cam, 128, 128, po.VARIANT_MESH, po.NORMALS_GEOMETRIC, [1, 2, 16], None)
+
+
+def case_shading(name):
+    return 2 if "materials_unit" in name else (1 if "materials" in name else 0)
+
+
 def only(names):
     """Generates the named cases and leaves every other fixture as it is (python3 oracle/gen_golden.py --only a,b)."""
     path = f"{GOLD}/generation_report.json"
     report = json.load(open(path)) if os.path.exists(path) else []
-    for (name, sc, cam, W, H, variant, nm, spp, crop) in config4_cases() + [tiny_materials_case()]:
+    for (name, sc, cam, W, H, variant, nm, spp, crop) in config4_cases() + [tiny_materials_case(), unit_materials_case()]:
         if name not in names:
             continue
-        fx, rep = render_case(name, sc, cam, W, H, variant, nm, spp, crop, shading_mode=1 if "materials" in name else 0)
+        fx, rep = render_case(name, sc, cam, W, H, variant, nm, spp, crop, shading_mode=case_shading(name))
         np.savez_compressed(f"{GOLD}/case_{name}.npz", **fx)
         report = [r for r in report if r.get("case") != name] + [rep]
     json.dump(report, open(path, "w"), indent=1)
@@ -338,8 +354,8 @@ def main():
         np.savez_compressed(f"{GOLD}/case_{name}.npz", **fx)
         report.append(rep)
 
-    for (name, sc, cam, W, H, variant, nm, spp, crop) in config4_cases() + [tiny_materials_case()]:
-        fx, rep = render_case(name, sc, cam, W, H, variant, nm, spp, crop, shading_mode=1 if "materials" in name else 0)
+    for (name, sc, cam, W, H, variant, nm, spp, crop) in config4_cases() + [tiny_materials_case(), unit_materials_case()]:
+        fx, rep = render_case(name, sc, cam, W, H, variant, nm, spp, crop, shading_mode=case_shading(name))
         np.savez_compressed(f"{GOLD}/case_{name}.npz", **fx)
         report.append(rep)
 

@@ -50,7 +50,9 @@ typedef struct PtoUniforms {
     int32_t normal_mode;  /* 0 = interpolated vertex normals (fs:165); 1 = geometric normal, the shader's alternative (fs:166) */
     int32_t shading_mode; /* 0 = the shader as it is (Phong lobe, material ignored, origin fixed);
                              1 = build-defined diffuse/emissive mode = the shader with the edits of
-                                 oracle/llvmpipe/edits/mesh_materials_geo.txt (pinned against llvmpipe running exactly that) */
+                                 oracle/llvmpipe/edits/mesh_materials_geo.txt (pinned against llvmpipe running exactly that);
+                             2 = the same with the Lambert bounce in the form of fs:272, rd = normalize(N + randomUnitVector())
+                                 (fs:57-65): oracle/llvmpipe/edits/mesh_materials_unit_geo.txt */
 } PtoUniforms;
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -300,17 +302,30 @@ static void shade(PixelCtx* p, v3* attenuation, v3* rd, v3 N) {
 /* Shade() of the "materials" variant (edits/mesh_materials_geo.txt, replacing fs:229): material = (r,g,b,e);
  * e > 0: emitter of radiance rgb*e, path ends; else Lambert of albedo rgb, cosine-weighted direction about N from the
  * shader's own GetTangentSpace/randomHemisphere(r1, 1.0) (fs:44-76), and the origin moves to the hit point (fs:274). */
-static void shade_materials(PixelCtx* p, const float* m, v3* attenuation, v3* ro, v3* rd, v3 P, v3 N, v3* emitted) {
+/* fs:57-65 randomUnitVector(): z uniform in [-1, 1), then a point on the circle of that height. */
+static v3 random_unit_vector(PixelCtx* p) {
+    float z = rng_rand01(p) * 2.0f - 1.0f;
+    float r = sqrtf(1.0f - z * z);
+    float a = (rng_rand01(p) * 2.0f) * 3.141592653589f;  /* M_PI as the shader defines it, fs:25 */
+    return V(lp_sincos(a, 1) * r, lp_sincos(a, 0) * r, z);
+}
+
+static void shade_materials(PixelCtx* p, const float* m, v3* attenuation, v3* ro, v3* rd, v3 P, v3 N, v3* emitted, int unit_form) {
     if (m[3] > 0.0f) {
         *emitted = mul(*attenuation, V(m[0] * m[3], m[1] * m[3], m[2] * m[3]));
         *attenuation = V(0.0f, 0.0f, 0.0f);
         return;
     }
-    float r1 = rng_rand01(p);
-    v3 c0, c1, c2;
-    tangent_space(N, &c0, &c1, &c2);
-    v3 h = random_hemisphere(p, r1, 1.0f);
-    *rd = add(add(scale(c0, h.x), scale(c1, h.y)), scale(c2, h.z));
+    if (unit_form) {
+        /* the Lambert bounce in the form of fs:272: rd = normalize(N + randomUnitVector()) */
+        *rd = normalize3(add(N, random_unit_vector(p)));
+    } else {
+        float r1 = rng_rand01(p);
+        v3 c0, c1, c2;
+        tangent_space(N, &c0, &c1, &c2);
+        v3 h = random_hemisphere(p, r1, 1.0f);
+        *rd = add(add(scale(c0, h.x), scale(c1, h.y)), scale(c2, h.z));
+    }
     *ro = add(P, scale(*rd, 0.0001f));
     *attenuation = mul(*attenuation, V(m[0], m[1], m[2]));
 }
@@ -345,7 +360,7 @@ static v3 trace_pixel(const PtoScene* sc, const PtoUniforms* u, int px, int py, 
         if (prim && level == 0) { prim->id = hit; prim->t = hit >= 0 ? rec_t : 1.0e38f; }
         if (hit >= 0) {
             if (u->shading_mode == 0) shade(&p, &energy, &rd, rec_n);
-            else shade_materials(&p, sc->materials + 4 * sc->material_ids[hit], &energy, &ro, &rd, rec_p, rec_n, &emitted);
+            else shade_materials(&p, sc->materials + 4 * sc->material_ids[hit], &energy, &ro, &rd, rec_p, rec_n, &emitted, u->shading_mode == 2);
         }
         int any_energy = (energy.x != 0.0f) || (energy.y != 0.0f) || (energy.z != 0.0f);
         if (!any_energy || hit < 0) break;

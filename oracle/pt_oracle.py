@@ -90,7 +90,7 @@ class Scene:
                         self.spheres.ctypes.data, self.materials.ctypes.data, self.material_ids.ctypes.data)
 
 
-SHADE_REFERENCE, SHADE_MATERIALS = 0, 1
+SHADE_REFERENCE, SHADE_MATERIALS, SHADE_MATERIALS_UNIT = 0, 1, 2
 
 
 def uniforms(camera12, width, height, num_triangles, depth=10, variant=VARIANT_MESH, normal_mode=NORMALS_VERTEX,

@@ -39,6 +39,9 @@ constexpr int kMaxDevices = 64;
 void* g_scratch_ptr[kMaxDevices] = {};  // device address of `scratch` on each GPU (each holds its own copy)
 std::mutex g_scratch_mutex;
 
+// the modes in which Shade() keeps the fetched material and moves the ray origin
+inline bool is_materials(PtShadingMode m) { return m == PT_SHADE_MATERIALS || m == PT_SHADE_MATERIALS_UNIT; }
+
 thread_local char g_error[512] = "";
 
 PtStatus fail(PtStatus code, const char* fmt, ...) {
@@ -143,7 +146,8 @@ struct PtContext {
     float split_factor = -1.f;            // < 0: chosen per kernel family, see pt_dispatch
     bool primary_reuse = true;
     int32_t lane_stack_limit = PT_LANE_STACK;  // PT_LANE_STACK_LIMIT=n (testing): a lane hands over to the per-wave walk earlier
-    bool lane_walk = true;                // PT_LANE_WALK=0: materials mode walks the hierarchy once per wave, not per lane
+    int lane_walk = 1;                    // materials mode: 1 = one hierarchy walk per lane, lanes decoupled; PT_LANE_WALK=2: per lane, all
+                                          // lanes of a wave in step; PT_LANE_WALK=0: one walk per wave
     bool auto_grid = true;                // PT_AUTO_GRID=0: PT_ACCEL_AUTO never picks the direction grid (for comparisons)
     bool keep_unreachable = false;        // PT_KEEP_UNREACHABLE=1: the loop walks all records (to measure the compaction)
     int32_t sched_win[4] = {-1, -1, -1, -1};  // window the costs were measured for
@@ -465,7 +469,7 @@ PtStatus fill_params(PtContext* ctx, PtKernelParams* p, const Program** prog_out
         const bool use_bvh = ctx->bvh_built && ctx->accel_mode != PT_ACCEL_BRUTE && ctx->accel_mode != PT_ACCEL_CULL &&
                              u.num_triangles == ctx->num_triangles &&
                              (ctx->accel_mode == PT_ACCEL_BVH ||
-                              u.num_triangles > (ctx->shading_mode == PT_SHADE_MATERIALS ? PT_BVH_AUTO_MIN_TRIANGLES_MOVING : PT_BVH_AUTO_MIN_TRIANGLES));
+                              u.num_triangles > (is_materials(ctx->shading_mode) ? PT_BVH_AUTO_MIN_TRIANGLES_MOVING : PT_BVH_AUTO_MIN_TRIANGLES));
         PT_REQUIRE(use_bvh || ctx->accel_mode != PT_ACCEL_BVH, PT_ERR_STATE, "the BVH covers all %d triangles but u_NumTriangles = %d",
                    ctx->num_triangles, u.num_triangles);
         p->shading_mode = (int32_t)ctx->shading_mode;
@@ -487,7 +491,7 @@ PtStatus fill_params(PtContext* ctx, PtKernelParams* p, const Program** prog_out
             p->grid_list = ctx->grid.list;
             p->grid_tris = ctx->d_tris_grid;
             p->grid_res = ctx->grid.res;
-        } else if (ctx->shading_mode == PT_SHADE_MATERIALS) {
+        } else if (is_materials(ctx->shading_mode)) {
             PT_REQUIRE(ctx->accel_mode != PT_ACCEL_CULL, PT_ERR_STATE, "PT_ACCEL_CULL serves rays from the camera only; PT_SHADE_MATERIALS moves the origin");
             PT_REQUIRE(ctx->d_materials != nullptr, PT_ERR_STATE, "PT_SHADE_MATERIALS but no material table: call pt_upload_materials first");
             PT_REQUIRE(ctx->num_material_ids == ctx->num_triangles, PT_ERR_STATE,
@@ -499,7 +503,7 @@ PtStatus fill_params(PtContext* ctx, PtKernelParams* p, const Program** prog_out
             p->materials = ctx->d_materials;
             p->material_ids = ctx->d_material_ids;
             if (use_bvh) {
-                p->lane_walk = ctx->lane_walk ? 1 : 0;
+                p->lane_walk = ctx->lane_walk;
                 p->lane_stack_limit = ctx->lane_stack_limit;
                 p->bvh_nodes_abs = ctx->bvh.nodes_abs;
                 p->bvh_tris_abs = ctx->bvh.sorted_tris_abs;
@@ -608,7 +612,7 @@ PtStatus pt_create(int32_t device, PtContext** out_ctx) {
     if (const char* g = getenv("PT_GRID_QUEUE")) ctx->grid_queue_override = atoi(g);
     if (const char* g = getenv("PT_FAIL_GRID_ALLOC")) ctx->fail_grid_alloc = atoi(g);
     if (const char* g = getenv("PT_GRID_RES")) ctx->grid_res_override = std::min(atoi(g), 8192);  // cell indices stay far below 2^32
-    if (const char* l = getenv("PT_LANE_WALK")) ctx->lane_walk = l[0] != '0';
+    if (const char* l = getenv("PT_LANE_WALK")) ctx->lane_walk = l[0] == '0' ? 0 : (l[0] == '2' ? 2 : 1);
     if (const char* l = getenv("PT_LANE_STACK_LIMIT")) ctx->lane_stack_limit = std::max(0, std::min(PT_LANE_STACK, atoi(l)));
     if (const char* k = getenv("PT_KEEP_UNREACHABLE")) ctx->keep_unreachable = k[0] == '1';
     if (const char* f = getenv("PT_SPLIT_FACTOR")) ctx->split_factor = (float)atof(f);  // for experiments
@@ -780,7 +784,7 @@ PtStatus pt_set_primary_reuse(PtContext* ctx, int32_t enable) {
 
 PtStatus pt_set_shading_mode(PtContext* ctx, PtShadingMode mode) {
     PT_REQUIRE(ctx != nullptr, PT_ERR_INVALID_ARGUMENT, "null context");
-    PT_REQUIRE(mode == PT_SHADE_REFERENCE || mode == PT_SHADE_MATERIALS, PT_ERR_INVALID_ARGUMENT, "unknown shading mode %d", (int)mode);
+    PT_REQUIRE(mode == PT_SHADE_REFERENCE || is_materials(mode), PT_ERR_INVALID_ARGUMENT, "unknown shading mode %d", (int)mode);
     ctx->shading_mode = mode;
     return PT_OK;
 }
@@ -1011,7 +1015,7 @@ PtStatus dispatch_range(PtContext* ctx, int32_t first_sample, int32_t num_sample
             const float base_factor = ctx->split_factor >= 0.f ? std::min(ctx->split_factor, (float)PT_MAX_SPLIT_FACTOR)
                                                                : ((p.bvh_nodes || p.bvh_nodes_abs) ? 4.0f : 1.0f);
             const bool splitting = ctx->sched_mode == 2 && num_samples > 1;
-            const int entry_bytes = ctx->shading_mode == PT_SHADE_MATERIALS && prog->kind != PT_PROGRAM_WORLD ? 16 : 8;  // what a parked sample takes
+            const int entry_bytes = is_materials(ctx->shading_mode) && prog->kind != PT_PROGRAM_WORLD ? 16 : 8;  // what a parked sample takes
             const size_t slot_bytes = (size_t)num_samples * PT_TILE_THREADS * (size_t)entry_bytes;
             const bool reuse = ctx->list_valid && ctx->list_samples == num_samples && ctx->list_base_factor == base_factor &&
                                ctx->list_entry_bytes == entry_bytes && ctx->list_age < 16 && ctx->cost_samples < 2 * ctx->list_basis;
@@ -1217,7 +1221,7 @@ PtStatus pt_dispatch_static(PtContext* ctx, int32_t first_sample, int32_t num_sa
     if (s != PT_OK) return s;
     if (probe) {
         const int32_t rest = num_samples - probe;
-        const int entry_bytes = ctx->shading_mode == PT_SHADE_MATERIALS && prog->kind != PT_PROGRAM_WORLD ? 16 : 8;
+        const int entry_bytes = is_materials(ctx->shading_mode) && prog->kind != PT_PROGRAM_WORLD ? 16 : 8;
         const size_t slot_bytes = (size_t)rest * PT_TILE_THREADS * (size_t)entry_bytes;
         s = begin_pass(ctx, &p, &prog, first_sample + probe * stride, rest, stride);
         if (s != PT_OK) return s;
@@ -1373,7 +1377,7 @@ PtStatus pt_verify_accel(PtContext* ctx, int32_t bounces, uint64_t result[3]) {
     PT_REQUIRE(prog->kind == PT_PROGRAM_MESH, PT_ERR_STATE, "pt_verify_accel checks the mesh search structures; the program in use traces spheres");
     PT_REQUIRE(p.num_triangles > 0, PT_ERR_STATE, "u_NumTriangles is 0: nothing to check");
     PT_REQUIRE(!p.cull, PT_ERR_UNSUPPORTED, "PT_ACCEL_CULL has no self-check");
-    const bool structure = p.shading_mode == (int32_t)PT_SHADE_MATERIALS ? p.bvh_nodes_abs != nullptr : (p.grid_cells || p.bvh_nodes || p.live_count);
+    const bool structure = p.shading_mode != (int32_t)PT_SHADE_REFERENCE ? p.bvh_nodes_abs != nullptr : (p.grid_cells || p.bvh_nodes || p.live_count);
     PT_REQUIRE(structure, PT_ERR_STATE, "the current modes select the plain loop over all triangles: there is no search structure to check "
                "(call pt_build_accel, or trace all uploaded triangles)");
     p.first_sample = 1;

@@ -38,7 +38,7 @@ struct PtTriRecordLayout {
 // PT_ACCEL_AUTO walks the hierarchy above these triangle counts (measured: 36 triangles: loop = walk for camera-origin rays,
 // loop 1.3x faster for rays with their own origins; 64 triangles: walk 2.8x faster; 968: 40x)
 #define PT_BVH_AUTO_MIN_TRIANGLES 48
-#define PT_BVH_AUTO_MIN_TRIANGLES_MOVING 128
+#define PT_BVH_AUTO_MIN_TRIANGLES_MOVING 96
 
 // Statistics counters are spread over many cache lines: every wave adds to them once, and with one address those
 // additions queue up behind each other in L2 (measured: 32,400 short waves took 0.83 ms for 0.12 ms of work).
@@ -160,7 +160,8 @@ struct PtKernelParams {
     const float* bvh_tris;              // triangle records in leaf order
     const int32_t* bvh_ids;             // triangle id of each leaf-order record
     const float* bvh_nodes_abs;         // LBVH records with absolute boxes (rays with their own origin)
-    int32_t lane_walk;                  // 1: one hierarchy walk per lane (incoherent rays) instead of one per wave
+    int32_t lane_walk;                  // one hierarchy walk per lane (incoherent rays) instead of one per wave: 1 = lanes decoupled
+                                        // (pt_render_decoupled_kernel), 2 = all lanes of a wave in step (pt_render_kernel<5, true>)
     int32_t lane_stack_limit;           // entries of a lane's stack that may be used (<= PT_LANE_STACK)
     const float* bvh_tris_abs;          // a, e1, e2 records in leaf order
     const float* spheres;               // 10 x 8 floats: per-sphere records for the current camera position (pt_prepare_spheres_kernel)

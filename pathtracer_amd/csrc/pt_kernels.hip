@@ -715,24 +715,34 @@ __device__ __forceinline__ void shade(Rng& rng, float& energy, v3& rd, v3 N) {
 // radiance rgb*e that ends the path; otherwise a Lambert surface of albedo rgb: cosine-weighted direction about N from
 // the shader's own GetTangentSpace / randomHemisphere(r1, 1.0) (fs:44-76) with its own rand01(), and the origin moves
 // to the hit point as in fs:274. Pinned against llvmpipe running the shader with exactly these statements edited in.
+// `unit_form` (wave-uniform: the shading mode) selects the Lambert bounce the reference carries at fs:272 instead,
+// rd = normalize(N + randomUnitVector()), with randomUnitVector() as at fs:57-65.
 __device__ __forceinline__ void shade_materials(Rng& rng, const float* __restrict__ materials, int mat, v3& energy, v3& emitted, v3& ro,
-                                                v3& rd, v3 P, v3 N) {
+                                                v3& rd, v3 P, v3 N, bool unit_form) {
     const float4 m = reinterpret_cast<const float4*>(materials)[mat];
     if (m.w > 0.0f) {
         emitted = V(energy.x * (m.x * m.w), energy.y * (m.y * m.w), energy.z * (m.z * m.w));
         energy = V(0.f, 0.f, 0.f);
         return;
     }
-    const float r1 = rng.rand01();
-    v3 helper = V(1.0f, 0.0f, 0.0f);
-    if (__builtin_fabsf(N.x) > 0.99f) helper = V(0.0f, 0.0f, 1.0f);
-    const v3 tangent = normalize3(cross3(N, helper));
-    const v3 binormal = normalize3(cross3(N, tangent));
-    const float cos_t = lp_pow(r1, 1.0f / (1.0f + 1.0f));
-    const float sin_t = ieee_sqrt(__builtin_fmaxf(0.0f, 1.0f - cos_t * cos_t));
-    const float phi = (rng.rand01() * 2.0f) * 3.141592653589f;
-    const v3 hemi = V(lp_sincos<true>(phi) * sin_t, cos_t, lp_sincos<false>(phi) * sin_t);
-    rd = (tangent * hemi.x + N * hemi.y) + binormal * hemi.z;
+    if (unit_form) {
+        // fs:57-65: z uniform in [-1, 1), then a point on the circle of that height
+        const float z = rng.rand01() * 2.0f - 1.0f;
+        const float r = ieee_sqrt(1.0f - z * z);
+        const float a = (rng.rand01() * 2.0f) * 3.141592653589f;
+        rd = normalize3(N + V(lp_sincos<true>(a) * r, lp_sincos<false>(a) * r, z));
+    } else {
+        const float r1 = rng.rand01();
+        v3 helper = V(1.0f, 0.0f, 0.0f);
+        if (__builtin_fabsf(N.x) > 0.99f) helper = V(0.0f, 0.0f, 1.0f);
+        const v3 tangent = normalize3(cross3(N, helper));
+        const v3 binormal = normalize3(cross3(N, tangent));
+        const float cos_t = lp_pow(r1, 1.0f / (1.0f + 1.0f));
+        const float sin_t = ieee_sqrt(__builtin_fmaxf(0.0f, 1.0f - cos_t * cos_t));
+        const float phi = (rng.rand01() * 2.0f) * 3.141592653589f;
+        const v3 hemi = V(lp_sincos<true>(phi) * sin_t, cos_t, lp_sincos<false>(phi) * sin_t);
+        rd = (tangent * hemi.x + N * hemi.y) + binormal * hemi.z;
+    }
     ro = P + rd * 0.0001f;
     energy = V(energy.x * m.x, energy.y * m.y, energy.z * m.z);
 }
@@ -941,7 +951,7 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
                 ++shaded;
                 if (MATERIALS) {
                     const v3 P = ro + rd * pend_t;  // recPoint, fs:163
-                    shade_materials(rng, p.materials, p.material_ids[pend_id], energy, emitted, ro, rd, P, pend_n);
+                    shade_materials(rng, p.materials, p.material_ids[pend_id], energy, emitted, ro, rd, P, pend_n, p.shading_mode == 2);
                 } else {
                     shade(rng, energy.x, rd, pend_n);
                 }
@@ -1019,6 +1029,301 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
     }
 }
 
+// ---- diffuse/emissive mode through the LBVH, lanes decoupled -------------------------------------------------------------
+// Rays that bounce diffusely from scattered points have little in common: the hierarchy walks of the 64 lanes of a wave differ
+// several-fold in length, and in pt_render_kernel<5, true> every lane waits for the longest walk of its wave before any of
+// them is shaded (measured: 15 % of the lanes active over the kernel). Here a lane is a small state machine and the wave's
+// loop only asks "what does each lane need next":
+//   WALK   one round of its own hierarchy walk: a few node steps, then the leaf it arrived at (same records, same slab
+//          arithmetic, same exact triangle test with the lowest-index rule as intersect_bvh_lanes, so the same hit);
+//   SHADE  its walk is over (or its sample starts from the reused camera-ray hit): it waits until PT_SHADE_BATCH lanes are
+//          waiting, or nobody walks any more, and then the wave runs Shade(), the end of the sample (fs:408-415) and the
+//          start of the next query for all of them at once;
+//   DONE   no samples left.
+// A lane that finishes a walk early goes on to its next bounce while its neighbours are still walking. The image is the
+// one pt_render_kernel<5, true> renders (and the all-triangles loop, and the shader): per pixel the samples are still folded
+// in order by the lane that owns the pixel.
+#ifndef PT_SHADE_BATCH
+#define PT_SHADE_BATCH 16
+#endif
+// node steps per round before the lane looks at its leaf (measured on three scenes: 2: +5 %, 3: 0, 5: -6 %, 8: -5 %, 16: +3 %,
+// unbounded: +12 % of the time at 3)
+#ifndef PT_WALK_NODE_STEPS
+#define PT_WALK_NODE_STEPS 5
+#endif
+
+struct LaneWalk {
+    uint32_t ref;  // node or leaf reference the lane looks at next
+    int sp;        // entries on the lane's stack
+    Hit h;
+    float ix, iy, iz, ox, oy, oz;  // reciprocal direction and origin x reciprocal, for the slab tests
+};
+
+__device__ __forceinline__ void walk_begin(LaneWalk& w, v3 ro, v3 rd) {
+    const float tiny = 1.0e-20f;
+    w.ix = __builtin_amdgcn_rcpf(__builtin_fabsf(rd.x) > tiny ? rd.x : __builtin_copysignf(tiny, rd.x));
+    w.iy = __builtin_amdgcn_rcpf(__builtin_fabsf(rd.y) > tiny ? rd.y : __builtin_copysignf(tiny, rd.y));
+    w.iz = __builtin_amdgcn_rcpf(__builtin_fabsf(rd.z) > tiny ? rd.z : __builtin_copysignf(tiny, rd.z));
+    w.ox = ro.x * w.ix; w.oy = ro.y * w.iy; w.oz = ro.z * w.iz;
+    w.ref = 0;  // root = internal node 0
+    w.sp = 0;
+    w.h.t = 1.0e38f; w.h.id = -1; w.h.u = 0.f; w.h.v = 0.f; w.h.ood = 0.f;
+}
+
+// One round of a lane's walk. Returns 0 = more to do, 1 = the walk is over (w.h is the closest hit), 2 = the lane's stack
+// is full (the caller repeats the query with the per-wave walk, which has room for any hierarchy).
+__device__ __forceinline__ int walk_round(const PtKernelParams& p, LaneWalk& w, v3 ro, v3 rd, uint32_t* __restrict__ my, unsigned& steps) {
+    const float4* __restrict__ nodes = reinterpret_cast<const float4*>(p.bvh_nodes_abs);
+    const float4* __restrict__ recs = reinterpret_cast<const float4*>(p.bvh_tris_abs);
+    const float ax = __builtin_fabsf(w.ix), ay = __builtin_fabsf(w.iy), az = __builtin_fabsf(w.iz);
+    for (int s = 0; s < PT_WALK_NODE_STEPS && !(w.ref & 0x80000000u); ++s) {
+        ++steps;
+        const size_t at = 4 * (size_t)w.ref;
+        const float4 n0 = nodes[at], n1 = nodes[at + 1], n2 = nodes[at + 2], n3 = nodes[at + 3];
+        const float limit = w.h.t * 1.0001f;
+        float m, t;
+        m = n0.w * ax; t = __builtin_fmaf(n0.x, w.ix, -w.ox); float lnear = t - m, lfar = t + m;
+        m = n1.x * ay; t = __builtin_fmaf(n0.y, w.iy, -w.oy); const float lny = t - m, lfy = t + m;
+        m = n1.y * az; t = __builtin_fmaf(n0.z, w.iz, -w.oz); const float lnz = t - m, lfz = t + m;
+        lnear = __builtin_fmaxf(__builtin_fmaxf(lnear, lny), __builtin_fmaxf(lnz, 0.0f));
+        lfar = __builtin_fminf(__builtin_fminf(lfar, lfy), __builtin_fminf(lfz, limit));
+        m = n2.y * ax; t = __builtin_fmaf(n1.z, w.ix, -w.ox); float rnear = t - m, rfar = t + m;
+        m = n2.z * ay; t = __builtin_fmaf(n1.w, w.iy, -w.oy); const float rny = t - m, rfy = t + m;
+        m = n2.w * az; t = __builtin_fmaf(n2.x, w.iz, -w.oz); const float rnz = t - m, rfz = t + m;
+        rnear = __builtin_fmaxf(__builtin_fmaxf(rnear, rny), __builtin_fmaxf(rnz, 0.0f));
+        rfar = __builtin_fminf(__builtin_fminf(rfar, rfy), __builtin_fminf(rfz, limit));
+        const bool hl = lnear <= lfar, hr = rnear <= rfar;
+        const uint32_t lref = __float_as_uint(n3.x), rref = __float_as_uint(n3.y);
+        if (hl && hr) {
+            const bool left_first = lnear <= rnear;
+            if (w.sp >= p.lane_stack_limit) return 2;
+            my[w.sp * 64] = left_first ? rref : lref;
+            ++w.sp;
+            w.ref = left_first ? lref : rref;
+        } else if (hl || hr) {
+            w.ref = hl ? lref : rref;
+        } else {
+            if (w.sp == 0) return 1;
+            --w.sp;
+            w.ref = my[w.sp * 64];
+        }
+    }
+    if (!(w.ref & 0x80000000u)) return 0;
+    // leaf: up to PT_BVH_LEAF_MAX consecutive records, requested together
+    const int first = (int)((w.ref & 0x7fffffffu) >> 3), count = (int)(w.ref & 7u) + 1;
+    for (int k = 0; k < count; ++k) {
+        ++steps;
+        const size_t at = 4 * (size_t)(first + k);
+        const float4 ra = recs[at], rb = recs[at + 1], rc = recs[at + 2], rdd = recs[at + 3];
+        // fs:136-168 as written: record = a.xyz e1.x | e1.yz e2.xy | e2.z - - - | - - - id
+        const v3 a = V(ra.x, ra.y, ra.z), e1 = V(ra.w, rb.x, rb.y), e2 = V(rb.z, rb.w, rc.x);
+        const v3 q = cross3(rd, e2);
+        const float det = dot3(e1, q);
+        const v3 ap = ro - a;
+        const v3 r = cross3(ap, e1);
+        const float u = dot3(ap, q);
+        const float v = dot3(rd, r);
+        if ((det >= 0.0001f) & (u >= 0.0f) & (v >= 0.0f) & ((u + v) <= det)) {
+            const float ood = ieee_rcp(det);
+            const float tt = dot3(e2, r) * ood;
+            const int id = (int)__float_as_uint(rdd.w);
+            if (tt > 0.0f && (tt < w.h.t || (tt == w.h.t && id < w.h.id))) {
+                w.h.t = tt; w.h.id = id; w.h.u = u; w.h.v = v; w.h.ood = ood;
+            }
+        }
+    }
+    if (w.sp == 0) return 1;
+    --w.sp;
+    w.ref = my[w.sp * 64];
+    return 0;
+}
+
+// waves per SIMD the register allocation must allow: the walk waits on dependent fetches most of the time, so a fifth wave
+// is worth the few registers it costs (measured: 4 -> 5: -15 % time, 6: no further gain)
+#ifndef PT_DECOUPLED_MIN_WAVES
+#define PT_DECOUPLED_MIN_WAVES 5
+#endif
+__global__ __launch_bounds__(64, PT_DECOUPLED_MIN_WAVES) void pt_render_decoupled_kernel(const PtKernelParams p) {
+    __shared__ uint32_t s_stack[PT_BVH_STACK];
+    __shared__ uint32_t s_lane_stack[PT_LANE_STACK * 64];
+    int x, y;
+    int tile = (int)blockIdx.x, sample_begin = 0, sample_count = p.num_samples, scratch_slot = -1;
+    if (p.items) {
+        if (blockIdx.x >= *(const kuint32*)p.sched_counts) return;
+        const kuint32* item = (const kuint32*)(p.items + blockIdx.x);
+        tile = (int)item[0]; sample_begin = (int)item[1]; sample_count = (int)item[2]; scratch_slot = (int)item[3];
+    }
+    const bool in_window = pixel_of_lane(p, tile, x, y);
+    const size_t pix = in_window ? ((size_t)y * p.width + x) : 0;
+    const v3 ro0 = V(p.ro[0], p.ro[1], p.ro[2]);
+    Rng rng;
+    rng.fcx = (float)x + 0.5f;
+    rng.fcy = (float)y + 0.5f;
+    const v3 rd0 = primary_direction(p, rng.fcx, rng.fcy);
+    float4 prev = make_float4(0.f, 0.f, 0.f, 1.f);
+    if (in_window && scratch_slot < 0) prev = reinterpret_cast<const float4*>(p.src)[pix];
+    float mr = prev.x, mg = prev.y, mb = prev.z;
+    float4* __restrict__ scratch = nullptr;
+    if (scratch_slot >= 0)
+        scratch = reinterpret_cast<float4*>(p.sample_scratch) + ((size_t)scratch_slot * p.num_samples + sample_begin) * PT_TILE_THREADS + threadIdx.x;
+    uint32_t* __restrict__ my = s_lane_stack + (threadIdx.x & 63);
+
+    int remaining = in_window ? sample_count : 0;
+    int sample = p.first_sample + sample_begin * p.sample_stride;
+    unsigned rays = 0, traced = 0, batches = 0, rounds = 0, shaded = 0, steps = 0, node_visits = 0, tri_tests = 0;
+
+    // the camera ray of the pixel, once (the shader has no pixel jitter): every sample starts from its hit
+    const bool reuse = p.primary_reuse != 0 && p.depth > 0;
+    v3 N0 = V(0.f, 0.f, 0.f);
+    float t0 = 1.0e38f;
+    int id0 = -1;
+    bool hit0 = false;
+    if (reuse && remaining > 0) {
+        bool overflow;
+        Hit h = intersect_bvh_lanes(p, ro0, rd0, s_lane_stack, overflow, steps);
+        if (overflow) h = intersect_bvh<true>(p, ro0, rd0, s_stack, node_visits, tri_tests);
+        hit0 = h.id >= 0;
+        if (hit0) N0 = mesh_normal(p, h);
+        t0 = h.t; id0 = h.id;
+        ++traced; ++rays;
+    }
+    if (__builtin_amdgcn_ballot_w64(reuse && remaining > 0)) ++batches;
+
+    auto fold = [&](float sr, float sg, float sb, int k) {
+        if (scratch_slot >= 0) {
+            scratch[(size_t)k * PT_TILE_THREADS] = make_float4(sr, sg, sb, 0.f);
+        } else if (p.accum_mode == 0) {
+            const float a = ieee_rcp((float)sample);
+            mr = mr + a * (sr - mr);
+            mg = mg + a * (sg - mg);
+            mb = mb + a * (sb - mb);
+        } else {
+            mr += sr; mg += sg; mb += sb;
+        }
+    };
+
+    // a pixel whose camera ray leaves the scene: every sample is the sky colour of that direction (fs:408-410 with energy 1)
+    if (reuse && !hit0 && remaining > 0) {
+        const float t = 0.5f * (rd0.y + 1.0f);
+        const float omt = 1.0f - t;
+        const float sr = omt + 0.5f * t, sg = omt + 0.7f * t, sb = omt + 1.0f * t;
+        rays += (unsigned)(remaining - 1);
+        for (int k = 0; k < sample_count; ++k) {
+            if (scratch_slot < 0 && p.accum_mode == 0 && mr == sr && mg == sg && mb == sb) break;  // further folds leave it as it is
+            fold(sr, sg, sb, k);
+            sample += p.sample_stride;
+        }
+        remaining = 0;
+    }
+
+    enum { WALK = 0, SHADE = 1, DONE = 2, FULL = 3 };
+    // path state of the sample in flight
+    v3 ro = ro0, rd = rd0;
+    v3 energy = V(1.0f, 1.0f, 1.0f), emitted = V(0.f, 0.f, 0.f);
+    int level = 0;
+    rng.samples = (float)sample;
+    rng.sx = 0.0f;
+    bool pend_hit = hit0;
+    v3 pend_n = N0;
+    float pend_t = t0;
+    int pend_id = id0;
+    LaneWalk w;
+    walk_begin(w, ro0, rd0);
+    int state = remaining > 0 ? SHADE : DONE;
+    if (state == SHADE && !reuse && p.depth > 0) {  // no reuse: the sample's first query is the camera ray itself
+        state = WALK;
+        ++traced; ++rays;
+    }
+
+    for (;;) {
+        const unsigned long long walking = __builtin_amdgcn_ballot_w64(state == WALK);
+        const unsigned long long waiting = __builtin_amdgcn_ballot_w64(state == SHADE);
+        if (!walking && !waiting) break;
+        if (waiting && (__builtin_popcountll(waiting) >= PT_SHADE_BATCH || !walking)) {
+            ++batches;
+            // Shade() of the pending hit, the end of the sample, the start of the next query: until the lane walks again or
+            // has no samples left (a sample that ends starts the next one from the reused camera-ray hit at once)
+            while (state == SHADE) {
+                bool done = p.depth <= 0;
+                if (!done) {
+                    if (pend_hit) {
+                        ++shaded;
+                        const v3 P = ro + rd * pend_t;  // recPoint, fs:163
+                        shade_materials(rng, p.materials, p.material_ids[pend_id], energy, emitted, ro, rd, P, pend_n, p.shading_mode == 2);
+                    }
+                    ++level;
+                    const bool spent = energy.x == 0.0f && energy.y == 0.0f && energy.z == 0.0f;
+                    done = !pend_hit || spent || level >= p.depth;
+                }
+                if (!done) {
+                    walk_begin(w, ro, rd);
+                    state = WALK;
+                    ++traced; ++rays;
+                    break;
+                }
+                // fs:408-415
+                const float t = 0.5f * (rd.y + 1.0f);
+                const float omt = 1.0f - t;
+                const float sr = energy.x * (omt + 0.5f * t) + emitted.x, sg = energy.y * (omt + 0.7f * t) + emitted.y,
+                            sb = energy.z * (omt + 1.0f * t) + emitted.z;
+                fold(sr, sg, sb, sample_count - remaining);
+                --remaining;
+                sample += p.sample_stride;
+                ro = ro0; rd = rd0; energy = V(1.0f, 1.0f, 1.0f); emitted = V(0.f, 0.f, 0.f); level = 0;
+                rng.samples = (float)sample;
+                rng.sx = 0.0f;
+                if (remaining <= 0) { state = DONE; break; }
+                if (reuse) {
+                    pend_hit = hit0; pend_n = N0; pend_t = t0; pend_id = id0;
+                    ++rays;  // the new sample's camera-ray query, answered by the reused result
+                } else if (p.depth > 0) {
+                    walk_begin(w, ro0, rd0);
+                    state = WALK;
+                    ++traced; ++rays;
+                    break;
+                }
+            }
+        }
+        if (state == WALK) {
+            const int r = walk_round(p, w, ro, rd, my, steps);
+            if (r == 2) state = FULL;
+            else if (r == 1) {
+                pend_hit = w.h.id >= 0;
+                pend_t = w.h.t; pend_id = w.h.id;
+                if (pend_hit) pend_n = mesh_normal(p, w.h);
+                state = SHADE;
+            }
+        }
+        // (very deep hierarchies) a lane whose own stack is full repeats its query with the per-wave walk
+        if (__builtin_amdgcn_ballot_w64(state == FULL)) {
+            if (state == FULL) {
+                const Hit h = intersect_bvh<true>(p, ro, rd, s_stack, node_visits, tri_tests);
+                pend_hit = h.id >= 0;
+                pend_t = h.t; pend_id = h.id;
+                if (pend_hit) pend_n = mesh_normal(p, h);
+                state = SHADE;
+            }
+        }
+        ++rounds;
+    }
+    if (in_window && scratch_slot < 0) {
+        const float alpha = p.accum_mode == 0 ? 1.0f : prev.w + (float)p.num_samples;
+        reinterpret_cast<float4*>(p.dst)[pix] = make_float4(mr, mg, mb, alpha);
+    }
+    const unsigned long long wave_rays = wave_sum(rays), wave_traced = wave_sum(traced), wave_steps = wave_sum(steps), wave_shaded = wave_sum(shaded);
+    if ((threadIdx.x & 63) == 0 && wave_rays) {
+        unsigned long long* counters = p.counters + (size_t)(blockIdx.x % PT_COUNTER_SLOTS) * PT_COUNTER_STRIDE;
+        atomicAdd(&counters[0], wave_rays);
+        atomicAdd(&counters[1], (unsigned long long)__builtin_amdgcn_readfirstlane(batches) * 64ull);  // lane slots of the query batches
+        atomicAdd(&counters[4], wave_traced);
+        if (p.tile_cost) atomicAdd(&p.tile_cost[tile], 2u * __builtin_amdgcn_readfirstlane(rounds) + 8u * __builtin_amdgcn_readfirstlane(batches));
+        atomicAdd(&counters[2], (unsigned long long)__builtin_amdgcn_readfirstlane(node_visits));
+        atomicAdd(&counters[3], (unsigned long long)__builtin_amdgcn_readfirstlane(tri_tests));
+        atomicAdd(&counters[5], wave_steps);
+        if (wave_shaded) atomicAdd(&counters[6], wave_shaded);
+    }
+}
+
 template <int KIND>
 __global__ __launch_bounds__(PT_TILE_THREADS) void pt_primary_kernel(const PtKernelParams p) {
     __shared__ uint32_t s_stack[KIND == 2 ? PT_TILE_WAVES : 1][KIND == 2 ? PT_BVH_STACK : 1];
@@ -1082,7 +1387,7 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_verify_kernel(const PtKern
                 const v3 N = mesh_normal(p, a);
                 if (MATERIALS) {
                     const v3 P = ro + rd * a.t;
-                    shade_materials(rng, p.materials, p.material_ids[a.id], energy, emitted, ro, rd, P, N);
+                    shade_materials(rng, p.materials, p.material_ids[a.id], energy, emitted, ro, rd, P, N, p.shading_mode == 2);
                     live = !(energy.x == 0.0f && energy.y == 0.0f && energy.z == 0.0f);
                 } else {
                     shade(rng, energy.x, rd, N);
@@ -1288,7 +1593,7 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_fold_samples_kernel(const 
     };
     // the folds form one dependent chain; the loads do not, so they are issued eight at a time ahead of it
     const size_t first = (size_t)blockIdx.x * p.num_samples * PT_TILE_THREADS + threadIdx.x;
-    if (p.shading_mode == 1) {
+    if (p.shading_mode != 0) {
         const float4* __restrict__ scratch = reinterpret_cast<const float4*>(p.sample_scratch) + first;
         int k = 0;
         for (; k + 8 <= p.num_samples; k += 8) {
@@ -1505,8 +1810,10 @@ hipError_t pt_launch_render(const PtKernelParams& p, int program_kind, hipStream
     if (p.win_w <= 0 || p.win_h <= 0 || p.num_samples <= 0) return hipSuccess;
     const dim3 grid(p.items ? p.max_items : window_tiles(p)), block(PT_TILE_THREADS);
     if (program_kind == 0) hipLaunchKernelGGL((pt_render_kernel<0, false>), grid, block, 0, stream, p);
-    else if (p.shading_mode == 1) {
-        if (p.bvh_nodes_abs && p.lane_walk) hipLaunchKernelGGL((pt_render_kernel<5, true>), grid, block, 0, stream, p);
+    else if (p.shading_mode != 0) {
+        // lane_walk: 1 = lanes decoupled (default), 2 = the per-lane walk with all lanes in step, 0 = one walk per wave
+        if (p.bvh_nodes_abs && p.lane_walk == 1 && PT_TILE_WAVES == 1) hipLaunchKernelGGL(pt_render_decoupled_kernel, grid, block, 0, stream, p);
+        else if (p.bvh_nodes_abs && p.lane_walk) hipLaunchKernelGGL((pt_render_kernel<5, true>), grid, block, 0, stream, p);
         else if (p.bvh_nodes_abs) hipLaunchKernelGGL((pt_render_kernel<2, true>), grid, block, 0, stream, p);
         else hipLaunchKernelGGL((pt_render_kernel<1, true>), grid, block, 0, stream, p);
     }
@@ -1522,7 +1829,7 @@ hipError_t pt_launch_render(const PtKernelParams& p, int program_kind, hipStream
 hipError_t pt_launch_verify(const PtKernelParams& p, hipStream_t stream) {
     if (p.win_w <= 0 || p.win_h <= 0) return hipSuccess;
     const dim3 grid(window_tiles(p)), block(PT_TILE_THREADS);
-    if (p.shading_mode == 1) {
+    if (p.shading_mode != 0) {
         if (p.bvh_nodes_abs && p.lane_walk) hipLaunchKernelGGL((pt_verify_kernel<5, true>), grid, block, 0, stream, p);
         else if (p.bvh_nodes_abs) hipLaunchKernelGGL((pt_verify_kernel<2, true>), grid, block, 0, stream, p);
         else return hipErrorInvalidValue;  // the materials mode without a hierarchy IS the all-triangles loop

@@ -150,10 +150,10 @@ class SceneData:
         tracer.upload_mesh(self.vertices, self.indices)
         tracer.set_normal_mode(self.normal_mode)
         tracer.set_uniforms(self.camera, self.num_triangles, depth)
-        if shading == "materials":
+        if shading in ("materials", "materials_unit"):
             tracer.upload_materials(self.material_table)
             tracer.upload_material_ids(self.material_ids)
-            tracer.set_shading_mode(capi.SHADE_MATERIALS)
+            tracer.set_shading_mode(capi.SHADE_MATERIALS if shading == "materials" else capi.SHADE_MATERIALS_UNIT)
         else:
             tracer.set_shading_mode(capi.SHADE_REFERENCE)
         if accel:

@@ -80,20 +80,33 @@ def test_multi_sample_dispatch_equals_frame_by_frame(tracer, name):
     t.program_destroy(prog)
 
 
-@pytest.fixture(scope="module")
-def wave_walk_tracer():
-    """A context whose materials mode walks the hierarchy once per wave (the default is once per lane)."""
+def _tracer_with_lane_walk(value):
     import os
     from pathtracer_amd import Tracer
     old = os.environ.get("PT_LANE_WALK")
-    os.environ["PT_LANE_WALK"] = "0"
+    os.environ["PT_LANE_WALK"] = value
     try:
-        t = Tracer(0)
+        return Tracer(0)
     finally:
         if old is None:
             del os.environ["PT_LANE_WALK"]
         else:
             os.environ["PT_LANE_WALK"] = old
+
+
+@pytest.fixture(scope="module")
+def wave_walk_tracer():
+    """A context whose materials mode walks the hierarchy once per wave (the default is once per lane, lanes decoupled)."""
+    t = _tracer_with_lane_walk("0")
+    yield t
+    t.close()
+
+
+@pytest.fixture(scope="module")
+def in_step_walk_tracer():
+    """A context whose materials mode walks the hierarchy once per lane with all lanes of a wave in step (the kernel the
+    decoupled one replaced as the default; kept for comparisons)."""
+    t = _tracer_with_lane_walk("2")
     yield t
     t.close()
 
@@ -177,21 +190,28 @@ def test_lane_walk_hands_over_when_its_stack_is_full(limit):
         t.close()
 
 
-@pytest.mark.parametrize("walk", ["lane", "wave"])
-def test_materials_golden_through_bvh(tracer, wave_walk_tracer, walk):
-    """The llvmpipe golden of the diffuse/emissive mode, traced through the LBVH with absolute boxes."""
+@pytest.mark.parametrize("name", ["cornell_materials_128", "cornell_materials_unit_128", "cornell_materials_tiny_96"])
+@pytest.mark.parametrize("walk", ["lane", "lane_in_step", "wave"])
+def test_materials_golden_through_bvh(tracer, wave_walk_tracer, in_step_walk_tracer, walk, name):
+    """The llvmpipe goldens of the diffuse/emissive modes, traced through the LBVH with absolute boxes by each of its three
+    walks: per lane with the lanes decoupled (default), per lane in step, per wave."""
     from pathtracer_amd import capi
-    fx = load_case("cornell_materials_128")
-    t = tracer if walk == "lane" else wave_walk_tracer
+    fx = load_case(name)
+    t = {"lane": tracer, "lane_in_step": in_step_walk_tracer, "wave": wave_walk_tracer}[walk]
     prog = setup_case(t, fx)
     t.build_accel()
     t.set_accel_mode(capi.ACCEL_BVH)
     t.reset_stats()
     t.dispatch(1, 16, 1)
     t.finish()
-    assert n_bit_mismatch(t.readback()[..., :3], fx["lp_rgb_16"]) == 0
+    last = max(int(k) for k in fx["spp"])
+    if last != 16:
+        t.target_clear()
+        t.dispatch(1, last, 1)
+        t.finish()
+    assert n_bit_mismatch(t.readback()[..., :3], fx[f"lp_rgb_{last}"]) == 0
     st = t.stats()
-    assert (st["grid_triangle_tests"] if walk == "lane" else st["bvh_node_fetches"]) > 0
+    assert (st["grid_triangle_tests"] if walk != "wave" else st["bvh_node_fetches"]) > 0
     t.set_accel_mode(capi.ACCEL_AUTO)
     t.set_shading_mode(0)
     t.program_destroy(prog)
@@ -476,6 +496,43 @@ def test_c1_full_size_against_llvmpipe_digests(tracer):
         t.dispatch(1, 16, 1)
         t.finish()
         assert digest() == gold["sha256"]["16"]
+    t.program_destroy(prog)
+
+
+@pytest.mark.parametrize("accel", [0, 2])
+def test_c1_materials_against_llvmpipe_digests(tracer, accel):
+    """Config C1's size in the diffuse/emissive mode: cornell_box.obj with the table the C++ host derives from cornell_box.mtl,
+    512x512, passes 1..16, against SHA-256 digests of what the reference shader with the recorded edits rendered on llvmpipe
+    (oracle/time_c1.py --materials) -- through the all-triangles loop (what PT_ACCEL_AUTO picks for 36 triangles) and through
+    the LBVH's per-lane walk; frame by frame, then as one dispatch, then from a work list."""
+    import hashlib
+    import json
+    import os
+    from helpers import GOLDEN
+    from pathtracer_amd.scenes import SceneData
+    gold = json.load(open(os.path.join(GOLDEN, "c1_cornell_512_materials.json")))
+    scene = SceneData("cornell", 512, 512)
+    assert n_bit_mismatch(scene.camera, np.asarray(gold["camera"], np.float32)) == 0
+    t = tracer
+    prog = scene.upload(t, shading="materials")
+    t.set_accel_mode(accel)
+    t.set_accum_mode(0)
+    t.target_create(512, 512)
+    digest = lambda: hashlib.sha256(t.readback().tobytes()).hexdigest()
+    done = 0
+    for k in (1, 4, 16):
+        for s in range(done + 1, k + 1):
+            t.dispatch(s, 1, 1)
+        t.finish()
+        done = k
+        assert digest() == gold["sha256"][str(k)], f"after {k} passes"
+    for _ in range(2):
+        t.target_clear()
+        t.dispatch(1, 16, 1)
+        t.finish()
+        assert digest() == gold["sha256"]["16"]
+    t.set_accel_mode(0)
+    t.set_shading_mode(0)
     t.program_destroy(prog)
 
 
