@@ -43,7 +43,16 @@ typedef enum PtStatus {
  * (pathtracing.fs:395-396): as committed it traces the 10 spheres ("world"); "mesh" is the other line. */
 typedef enum PtProgramKind {
     PT_PROGRAM_WORLD = 0, /* IntersectWorld, pathtracing.fs:83-121, call at :395 */
-    PT_PROGRAM_MESH = 1   /* IntersectMesh,  pathtracing.fs:125-174, call at :396 */
+    PT_PROGRAM_MESH = 1,  /* IntersectMesh,  pathtracing.fs:125-174, call at :396 */
+    PT_PROGRAM_CPU_TRACER = 2 /* not a shader: the reference's CPU tracer, Scene::color (PathTracer.cpp:932-1052) with scatter
+                             (:830-852), compiled out of the reference's own build by #define USE_GLSL (:1246). Spheres AND mesh in
+                             one scene (the mesh takes material 0), camera rays through pixel corners (:742-745), Lambert bounce
+                             N + randomUnitVector() from the hit point, other material types pass the ray on, sky
+                             (1-t) + (1, 0.7, 0.5) t, running SUM per pixel whatever pt_set_accum_mode says. Its random numbers
+                             come from a counter-based generator keyed by (seed, pixel, sample index) instead of the reference's
+                             serial rand() stream, so its parity with the reference is statistical (per-pixel mean and variance);
+                             see pt_set_cpu_tracer. Vertex normals as uploaded; no search structure (the reference's own
+                             bounding-box test, then every triangle). */
 } PtProgramKind;
 
 /* Shading normal of a mesh hit. */
@@ -213,6 +222,9 @@ PtStatus pt_set_window(PtContext* ctx, int32_t x0, int32_t y0, int32_t w, int32_
  * merged exactly by a sum. count <= 1 switches it off. */
 PtStatus pt_set_row_interleave(PtContext* ctx, int32_t block_rows, int32_t index, int32_t count);
 PtStatus pt_set_accum_mode(PtContext* ctx, PtAccumMode mode);
+/* PT_PROGRAM_CPU_TRACER only: seed of its random number generator (default 1) and the camera ray's maxt, far - near of
+ * Camera::initialize (PathTracer.cpp:709-716, 745; default 100 - 0.1 as at :1161). Replaces srand() (PathTracer.cpp:1216). */
+PtStatus pt_set_cpu_tracer(PtContext* ctx, uint32_t seed, float ray_max_t);
 
 /* ---- per-frame: replaces PathTracer.cpp:1370-1403 ------------------------------------------------------ */
 

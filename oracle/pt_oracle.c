@@ -415,6 +415,183 @@ PTO_API uint64_t pto_render(const PtoScene* sc, const PtoUniforms* u, int first_
     return rays;
 }
 
+/* ------------------------------------------------------------------------------------------------ */
+/* The reference's CPU tracer (PathTracer.cpp:932-1052 Scene::color, :830-852 scatter, :595-640 Sphere::hit, :562-586  */
+/* Mesh::hit, :170-190 AABB::test, :101-152 HitRecord::hit, :742-745 Camera::generateRay), restated with a             */
+/* counter-based random number generator in place of its serial libc rand() stream, so that pixels and samples are      */
+/* independent and a parallel implementation can be compared bit for bit. PARITY of this restatement against the        */
+/* reference itself is STATISTICAL (tests/golden/cpu_tracer_stats.npz: per-pixel mean and variance from the reference's */
+/* own code, compiled from where it lies: oracle/_ref/cpu_tracer). Deviations, all forced by the generator: (1) the     */
+/* random numbers; (2) cos/sin of randomUnitVector() are the polynomial forms above instead of libm's cosf/sinf.        */
+
+/* float3::dot / length / normalize (PathTracer.cpp:58-62): sums left to right */
+static inline float dotc(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+static inline v3 normalizec(v3 a) { return scale(a, 1.0f / sqrtf((a.x * a.x + a.y * a.y) + a.z * a.z)); }
+
+static inline uint32_t pcg_hash(uint32_t x) {
+    uint32_t state = x * 747796405u + 2891336453u;
+    uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+typedef struct { uint32_t key, draw; } CtrRng;
+/* nextFloat(0, 1) (PathTracer.cpp:765-768): (float)rand() / (float)RAND_MAX with a 31-bit value; (float)RAND_MAX = 2^31 */
+static inline float ctr_next(CtrRng* r) {
+    uint32_t h = pcg_hash(r->key + pcg_hash(r->draw++));
+    return (float)(h >> 1) / 2147483648.0f;
+}
+
+typedef struct { v3 o, d; float mint, maxt; } RayC;
+typedef struct { v3 point, normal; float t; } RecC;
+
+static int cpu_sphere_hit(const float* s, const RayC* ray, RecC* rec) {
+    v3 c = V(s[0], s[1], s[2]);
+    float radius = s[3];
+    v3 to = sub(ray->o, c);
+    float A = dotc(ray->d, ray->d), B = dotc(to, ray->d), C = dotc(to, to) - radius * radius;
+    float disc = B * B - A * C;
+    if (disc > 0.0f) {
+        float root = sqrtf(disc);
+        float temp = (-B - root) / A;
+        if (temp < ray->maxt && temp > ray->mint) {
+            rec->point = add(ray->o, scale(ray->d, temp));
+            rec->normal = scale(sub(rec->point, c), 1.0f / radius);
+            rec->t = temp;
+            return 1;
+        }
+        float temp2 = (-B + root) / A;
+        if (temp2 < ray->maxt && temp2 > ray->mint) {
+            rec->point = add(ray->o, scale(ray->d, temp2));
+            rec->normal = scale(sub(rec->point, c), 1.0f / radius);
+            rec->t = temp2;
+            return 1;
+        }
+    }
+    return 0;
+}
+
+static int cpu_aabb_test(const float* lo, const float* hi, const RayC* ray) {
+    float tmin = ray->mint, tmax = ray->maxt;
+    const float o[3] = {ray->o.x, ray->o.y, ray->o.z}, d[3] = {ray->d.x, ray->d.y, ray->d.z};
+    for (int i = 0; i < 3; i++) {
+        if (fabsf(d[i]) < 0.001f) {
+            if (o[i] < lo[i] || o[i] > hi[i]) return 0;
+        } else {
+            float ood = 1.0f / d[i];
+            float t1 = (lo[i] - o[i]) * ood, t2 = (hi[i] - o[i]) * ood;
+            if (t1 > t2) { float x = t1; t1 = t2; t2 = x; }
+            if (t1 > tmin) tmin = t1;
+            if (t2 < tmax) tmax = t2;
+            if (tmin > tmax) return 0;
+        }
+    }
+    return 1;
+}
+
+static v3 cpu_color(const PtoScene* sc, int num_triangles, const float* lo, const float* hi, RayC ray, int depth, CtrRng* rng, uint64_t* rays) {
+    v3 energy = V(1.0f, 1.0f, 1.0f);
+    for (int level = 0; level < depth; ++level) {
+        RecC rec;
+        rec.point = V(0, 0, 0); rec.normal = V(0, 0, 0); rec.t = 0.0f;
+        int hit_index = -1;
+        (*rays)++;
+        for (int i = 0; i < 10; i++)
+            if (cpu_sphere_hit(sc->spheres + 4 * i, &ray, &rec)) { ray.maxt = rec.t; hit_index = i; }
+        if (num_triangles > 0) {
+            RayC r2 = ray;   /* Mesh::hit takes the ray by value */
+            int has = 0;
+            if (cpu_aabb_test(lo, hi, &r2)) {
+                for (int i = 0; i < num_triangles; i++) {
+                    const float* pa = sc->vertices + 6 * sc->indices[3 * i];
+                    const float* pb = sc->vertices + 6 * sc->indices[3 * i + 1];
+                    const float* pc = sc->vertices + 6 * sc->indices[3 * i + 2];
+                    v3 a = V(pa[0], pa[1], pa[2]);
+                    v3 e1 = sub(V(pb[0], pb[1], pb[2]), a), e2 = sub(V(pc[0], pc[1], pc[2]), a);
+                    v3 q = cross3(r2.d, e2);
+                    float det = dotc(e1, q);
+                    if (det < 0.0001f) continue;
+                    v3 ap = sub(r2.o, a);
+                    float u = dotc(ap, q);
+                    if (u < 0.0f || u > det) continue;
+                    v3 r = cross3(ap, e1);
+                    float v = dotc(r2.d, r);
+                    if (v < 0.0f || (u + v) > det) continue;
+                    float ood = 1.0f / det;
+                    float temp = dotc(e2, r) * ood;
+                    if (temp > r2.mint && temp < r2.maxt) {
+                        r2.maxt = temp;
+                        rec.t = temp;
+                        rec.point = add(r2.o, scale(r2.d, temp));
+                        float uy = u * ood, uz = v * ood, ux = (1.0f - uy) - uz;
+                        v3 n = add(add(scale(V(pa[3], pa[4], pa[5]), ux), scale(V(pb[3], pb[4], pb[5]), uy)), scale(V(pc[3], pc[4], pc[5]), uz));
+                        rec.normal = normalizec(n);
+                        has = 1;
+                    }
+                }
+            }
+            if (has) { ray.maxt = rec.t; hit_index = 0; }
+        }
+        if (hit_index < 0) break;
+        const float* m = sc->materials + 4 * hit_index;
+        v3 attenuation = V(1.0f, 1.0f, 1.0f);
+        /* scatter(), PathTracer.cpp:830-852 */
+        ray.o = add(rec.point, scale(rec.normal, 0.001f));
+        ray.mint = 0.0f;
+        ray.maxt = 3.402823466e+38f;
+        if (m[3] == 0.0f) {  /* Material::LAMBERT */
+            float z = ctr_next(rng) * 2.0f - 1.0f;
+            float a = (ctr_next(rng) * 2.0f) * 3.14159274f;
+            float r = sqrtf(1.0f - z * z);
+            v3 unit = V(lp_sincos(a, 1) * r, lp_sincos(a, 0) * r, z);
+            ray.d = normalizec(add(rec.normal, unit));
+            attenuation = V(m[0], m[1], m[2]);
+        }
+        energy = mul(energy, attenuation);
+        if ((energy.x + energy.y) + energy.z == 0.0f) break;
+    }
+    float t = 0.5f * (ray.d.y + 1.0f);
+    v3 sky = V((1.0f - t) + 1.0f * t, (1.0f - t) + 0.7f * t, (1.0f - t) + 0.5f * t);
+    return mul(energy, sky);
+}
+
+/* Running SUM of the samples first_sample, first_sample + stride, ... (count of them) of every pixel of the window, added
+ * to rgba_sum (4 floats per pixel, row 0 = bottom; the 4th is the number of samples folded in). Pixel-order layout; the
+ * reference's accumulationBuffer holds the same sums in its tile-traversal order (PathTracer.cpp:1326-1357). */
+PTO_API uint64_t pto_cpu_tracer(const PtoScene* sc, const PtoUniforms* u, float max_t, uint32_t seed, int first_sample, int stride,
+                                int count, float* rgba_sum, int x0, int y0, int w, int h) {
+    FpGuard g = fp_enter();
+    uint64_t rays = 0;
+    float lo[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f}, hi[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+    for (int i = 0; i < sc->num_vertices; i++)
+        for (int k = 0; k < 3; k++) {
+            float c = sc->vertices[6 * i + k];
+            if (c < lo[k]) lo[k] = c;
+            if (c > hi[k]) hi[k] = c;
+        }
+    v3 pos = V(u->cam_pos[0], u->cam_pos[1], u->cam_pos[2]), llc = V(u->cam_llc[0], u->cam_llc[1], u->cam_llc[2]);
+    v3 hor = V(u->cam_hor[0], u->cam_hor[1], u->cam_hor[2]), ver = V(u->cam_ver[0], u->cam_ver[1], u->cam_ver[2]);
+    for (int y = y0; y < y0 + h; y++) {
+        for (int x = x0; x < x0 + w; x++) {
+            float* px = rgba_sum + 4 * ((size_t)y * u->width + x);
+            /* Camera::generateRay(float(x), float(y)): through the pixel's CORNER, not its centre */
+            float fx = (float)x / (float)u->width, fy = (float)y / (float)u->height;
+            RayC ray0;
+            ray0.o = pos;
+            ray0.d = normalizec(sub(add(add(llc, scale(hor, fx)), scale(ver, fy)), pos));
+            ray0.mint = 0.0f;
+            ray0.maxt = max_t;
+            for (int s = 0; s < count; s++) {
+                CtrRng rng;
+                rng.key = pcg_hash(seed + pcg_hash((uint32_t)(y * u->width + x))) + pcg_hash(0x9E3779B9u * (uint32_t)(first_sample + s * stride));
+                rng.draw = 0;
+                v3 c = cpu_color(sc, u->num_triangles, lo, hi, ray0, u->depth, &rng, &rays);
+                px[0] += c.x; px[1] += c.y; px[2] += c.z; px[3] += 1.0f;
+            }
+        }
+    }
+    fp_leave(g);
+    return rays;
+}
+
 /* Primary-hit map of the same window: ids (int32, -1 = miss), t (1e38 on a miss) and the primary direction. */
 PTO_API void pto_primary(const PtoScene* sc, const PtoUniforms* u, int32_t* ids, float* ts, float* rds,
                          int x0, int y0, int w, int h) {

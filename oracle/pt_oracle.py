@@ -51,6 +51,9 @@ def lib():
         L.pto_primary.restype = None
         L.pto_primary.argtypes = [C.POINTER(PtoScene), C.POINTER(PtoUniforms), C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_int, C.c_int, C.c_int, C.c_int]
+        L.pto_cpu_tracer.restype = C.c_uint64
+        L.pto_cpu_tracer.argtypes = [C.POINTER(PtoScene), C.POINTER(PtoUniforms), C.c_float, C.c_uint32, C.c_int, C.c_int, C.c_int,
+                                     C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.pto_rng_stream.restype = None
         L.pto_rng_stream.argtypes = [C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]
         L.pto_camera.restype = None
@@ -171,6 +174,20 @@ def render_sum(scene, u, first_sample, stride, count, rgba_sum=None, window=None
     sc = scene.c_struct()
     L = lib()
     rays = _parallel(lambda ya, hh: L.pto_render_sum(C.byref(sc), C.byref(u), first_sample, stride, count,
+                                                     rgba_sum.ctypes.data, x0, ya, w, hh), _row_chunks(y0, h, threads))
+    return rgba_sum, int(sum(rays))
+
+
+def cpu_tracer(scene, u, first_sample, stride, count, rgba_sum=None, max_t=99.9, seed=1, window=None, threads=1):
+    """The reference's CPU tracer (Scene::color) restated with a counter-based generator: running sums of `count` samples added
+    to rgba_sum ([H, W, 4]: rgb sums + the number of samples); returns (rgba_sum, rays)."""
+    W, H = u.width, u.height
+    if rgba_sum is None:
+        rgba_sum = np.zeros((H, W, 4), np.float32)
+    x0, y0, w, h = window if window else (0, 0, W, H)
+    sc = scene.c_struct()
+    L = lib()
+    rays = _parallel(lambda ya, hh: L.pto_cpu_tracer(C.byref(sc), C.byref(u), max_t, seed, first_sample, stride, count,
                                                      rgba_sum.ctypes.data, x0, ya, w, hh), _row_chunks(y0, h, threads))
     return rgba_sum, int(sum(rays))
 

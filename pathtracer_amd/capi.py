@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpt_hip.so")
 
 PT_OK = 0
 PT_ERR_INVALID_ARGUMENT, PT_ERR_HIP, PT_ERR_STATE, PT_ERR_NO_DEVICE, PT_ERR_UNSUPPORTED = 1, 2, 3, 4, 5
-PROGRAM_WORLD, PROGRAM_MESH = 0, 1
+PROGRAM_WORLD, PROGRAM_MESH, PROGRAM_CPU_TRACER = 0, 1, 2
 NORMALS_VERTEX, NORMALS_GEOMETRIC = 0, 1
 ACCUM_MEAN, ACCUM_SUM = 0, 1
 ACCEL_AUTO, ACCEL_BRUTE, ACCEL_BVH, ACCEL_CULL, ACCEL_GRID = 0, 1, 2, 3, 4
@@ -66,6 +66,7 @@ SIGNATURES = {
     "pt_set_window": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "pt_set_row_interleave": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "pt_set_accum_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "pt_set_cpu_tracer": (C.c_int, [C.c_void_p, C.c_uint32, C.c_float]),
     "pt_set_uniforms": (C.c_int, [C.c_void_p, C.POINTER(PtUniforms)]),
     "pt_dispatch": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "pt_dispatch_static": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
@@ -206,6 +207,9 @@ class Tracer:
 
     def set_accum_mode(self, mode):
         check(self._lib.pt_set_accum_mode(self._ctx, mode), self._lib)
+
+    def set_cpu_tracer(self, seed=1, ray_max_t=99.9):
+        check(self._lib.pt_set_cpu_tracer(self._ctx, seed, ray_max_t), self._lib)
 
     # -- per frame
     def set_uniforms(self, camera12, num_triangles, depth=10):

@@ -102,6 +102,9 @@ struct PtContext {
     int32_t num_material_ids = 0;
     int32_t max_material_id = -1;
     float mesh_extent = 0.f;        // largest absolute vertex coordinate
+    float mesh_bounds[6] = {0, 0, 0, 0, 0, 0};  // min, max over the vertex positions (Mesh::bounds of the reference's CPU tracer)
+    uint32_t cpu_seed = 1;          // PT_PROGRAM_CPU_TRACER
+    float cpu_max_t = 100.f - 0.1f;
     PtShadingMode shading_mode = PT_SHADE_REFERENCE;
     bool records_valid = false;
     bool static_records_valid = false;  // normals and origin-independent records: written after an upload, kept over camera moves
@@ -447,6 +450,27 @@ PtStatus fill_params(PtContext* ctx, PtKernelParams* p, const Program** prog_out
     p->normal_mode = (int32_t)ctx->normal_mode;
     p->counters = ctx->d_counters;
     p->primary_reuse = ctx->primary_reuse ? 1 : 0;
+    if (prog->kind == PT_PROGRAM_CPU_TRACER) {
+        PT_REQUIRE(u.num_triangles >= 0 && u.num_triangles <= ctx->num_triangles, PT_ERR_INVALID_ARGUMENT,
+                   "u_NumTriangles = %d but %d triangles are uploaded", u.num_triangles, ctx->num_triangles);
+        PT_REQUIRE(ctx->have_spheres, PT_ERR_STATE, "no spheres uploaded: call pt_upload_spheres first");
+        PT_REQUIRE(ctx->d_materials != nullptr && ctx->num_materials >= 10, PT_ERR_STATE,
+                   "the CPU tracer's scene has one material per sphere: upload 10 materials (r, g, b, type) first");
+        p->num_triangles = u.num_triangles;
+        if (u.num_triangles > 0) {
+            PtStatus s = ensure_records(ctx);
+            if (s != PT_OK) return s;
+        }
+        p->tris_abs = ctx->d_tris_abs;
+        p->vnormals = ctx->d_vnormals;
+        p->materials = ctx->d_materials;
+        p->raw_spheres = ctx->d_spheres;
+        memcpy(p->cpu_bounds, ctx->mesh_bounds, sizeof p->cpu_bounds);
+        p->cpu_max_t = ctx->cpu_max_t;
+        p->cpu_seed = ctx->cpu_seed;
+        *prog_out = prog;
+        return PT_OK;
+    }
     if (prog->kind == PT_PROGRAM_MESH) {
         PT_REQUIRE(u.num_triangles >= 0 && u.num_triangles <= ctx->num_triangles, PT_ERR_INVALID_ARGUMENT,
                    "u_NumTriangles = %d but %d triangles are uploaded", u.num_triangles, ctx->num_triangles);
@@ -652,7 +676,7 @@ PtStatus pt_set_stream(PtContext* ctx, void* hip_stream) {
 PtStatus pt_program_create(PtContext* ctx, PtProgramKind kind, uint32_t* out_program) {
     PT_REQUIRE(ctx != nullptr && out_program != nullptr, PT_ERR_INVALID_ARGUMENT, "null argument");
     *out_program = 0;
-    PT_REQUIRE(kind == PT_PROGRAM_WORLD || kind == PT_PROGRAM_MESH, PT_ERR_INVALID_ARGUMENT, "unknown program kind %d", (int)kind);
+    PT_REQUIRE(kind == PT_PROGRAM_WORLD || kind == PT_PROGRAM_MESH || kind == PT_PROGRAM_CPU_TRACER, PT_ERR_INVALID_ARGUMENT, "unknown program kind %d", (int)kind);
     Program p;
     p.handle = ctx->next_program;
     p.kind = kind;
@@ -750,6 +774,13 @@ PtStatus pt_upload_mesh(PtContext* ctx, const float* vertices, int32_t num_verti
             if (c > extent && c < 3.0e38f) extent = c;
         }
     ctx->mesh_extent = extent;
+    for (int k = 0; k < 3; ++k) { ctx->mesh_bounds[k] = 3.402823466e+38f; ctx->mesh_bounds[3 + k] = -3.402823466e+38f; }
+    for (size_t v = 0; v < (size_t)num_vertices; ++v)
+        for (int k = 0; k < 3; ++k) {
+            const float c = vertices[6 * v + k];
+            if (c < ctx->mesh_bounds[k]) ctx->mesh_bounds[k] = c;
+            if (c > ctx->mesh_bounds[3 + k]) ctx->mesh_bounds[3 + k] = c;
+        }
     return PT_OK;
 }
 
@@ -954,6 +985,14 @@ PtStatus pt_set_accum_mode(PtContext* ctx, PtAccumMode mode) {
     return PT_OK;
 }
 
+PtStatus pt_set_cpu_tracer(PtContext* ctx, uint32_t seed, float ray_max_t) {
+    PT_REQUIRE(ctx != nullptr, PT_ERR_INVALID_ARGUMENT, "null context");
+    PT_REQUIRE(ray_max_t > 0.f, PT_ERR_INVALID_ARGUMENT, "ray_max_t must be positive; got %g", (double)ray_max_t);
+    ctx->cpu_seed = seed;
+    ctx->cpu_max_t = ray_max_t;
+    return PT_OK;
+}
+
 PtStatus pt_set_uniforms(PtContext* ctx, const PtUniforms* uniforms) {
     PT_REQUIRE(ctx != nullptr && uniforms != nullptr, PT_ERR_INVALID_ARGUMENT, "null argument");
     PT_REQUIRE(uniforms->num_triangles >= 0, PT_ERR_INVALID_ARGUMENT, "negative u_NumTriangles");
@@ -994,7 +1033,7 @@ PtStatus dispatch_range(PtContext* ctx, int32_t first_sample, int32_t num_sample
     // Tile order: the costs measured by the previous dispatch of this same window put the expensive tiles first.
     // It is only a scheduling hint (any order renders the same image), so stale costs after a camera or scene change
     // are harmless.
-    if (ctx->sched_mode != 0) {
+    if (ctx->sched_mode != 0 && prog->kind != PT_PROGRAM_CPU_TRACER) {
         const int tiles = PT_TILES_ACROSS(ctx->win[2]) * PT_TILES_ACROSS(ctx->win[3]);
         const bool same_window = memcmp(ctx->sched_win, ctx->win, sizeof ctx->win) == 0;
         if (ctx->sched_have_cost && same_window) {
@@ -1097,7 +1136,7 @@ PtStatus dispatch_range(PtContext* ctx, int32_t first_sample, int32_t num_sample
 PtStatus end_pass(PtContext* ctx, PtKernelParams& p, const Program* prog, int32_t num_samples) {
     // Camera-ray hits of this view: read if an earlier dispatch left them, written otherwise (reference shading only; the
     // materials mode also needs the distance).
-    const bool cache_usable = ctx->primary_cache_enabled && ctx->primary_reuse && p.depth > 0 &&
+    const bool cache_usable = ctx->primary_cache_enabled && ctx->primary_reuse && p.depth > 0 && prog->kind != PT_PROGRAM_CPU_TRACER &&
                               (prog->kind == PT_PROGRAM_WORLD || ctx->shading_mode == PT_SHADE_REFERENCE);
     if (cache_usable) {
         PtContext::PrimaryCacheKey key;
@@ -1151,7 +1190,9 @@ PtStatus pt_dispatch(PtContext* ctx, int32_t first_sample, int32_t num_samples, 
     // box, and far worse where few tiles carry the work. Its first samples are therefore rendered on their own; the costs
     // they record schedule the rest. Samples are folded in the same order either way, so the image does not change.
     const bool same_window = memcmp(ctx->sched_win, ctx->win, sizeof ctx->win) == 0;
-    const bool blind = ctx->sched_mode == 2 && (!ctx->sched_have_cost || !same_window || ctx->costs_stale);
+    const Program* current = find_program(ctx, ctx->current_program);
+    const bool blind = ctx->sched_mode == 2 && (!ctx->sched_have_cost || !same_window || ctx->costs_stale) &&
+                       !(current && current->kind == PT_PROGRAM_CPU_TRACER);
     if (blind && num_samples >= 4 * PT_PROBE_SAMPLES) {
         ctx->sched_have_cost = false;  // stale costs are dropped: the probe starts them afresh
         s = dispatch_range(ctx, first_sample, PT_PROBE_SAMPLES, stride);
@@ -1204,7 +1245,9 @@ PtStatus pt_dispatch_static(PtContext* ctx, int32_t first_sample, int32_t num_sa
     // costs they record schedule the rest -- with the launches sized for the largest list the array can hold instead of
     // the scheduler's counts, which are not read back. Any list that covers every (tile, sample) once renders the image
     // pt_dispatch renders.
-    const int32_t probe = (ctx->sched_mode == 2 && num_samples >= 4 * PT_PROBE_SAMPLES) ? PT_PROBE_SAMPLES : 0;
+    const Program* current = find_program(ctx, ctx->current_program);
+    const bool plain = current && current->kind == PT_PROGRAM_CPU_TRACER;   // (no work list: one launch)
+    const int32_t probe = (ctx->sched_mode == 2 && num_samples >= 4 * PT_PROBE_SAMPLES && !plain) ? PT_PROBE_SAMPLES : 0;
     s = begin_pass(ctx, &p, &prog, first_sample, probe ? probe : num_samples, stride);
     if (s != PT_OK) return s;
     if (ctx->timing) {
@@ -1293,6 +1336,7 @@ PtStatus pt_readback_primary(PtContext* ctx, int32_t* ids, float* t) {
     const Program* prog = nullptr;
     s = fill_params(ctx, &p, &prog);
     if (s != PT_OK) return s;
+    PT_REQUIRE(prog->kind != PT_PROGRAM_CPU_TRACER, PT_ERR_UNSUPPORTED, "pt_readback_primary serves the shader programs, not PT_PROGRAM_CPU_TRACER");
     p.out_ids = ctx->d_ids;
     p.out_t = ctx->d_t;
     const size_t n = (size_t)ctx->width * ctx->height;

@@ -182,6 +182,10 @@ struct PtKernelParams {
     int32_t primary_cache_valid;        // 1: read it; 0: evaluate the camera ray and write it
     int32_t* out_ids;                   // primary pass only
     float* out_t;                       // primary pass only
+    const float* raw_spheres;           // PT_PROGRAM_CPU_TRACER: the 10 spheres as uploaded (cx, cy, cz, r)
+    float cpu_bounds[6];                // PT_PROGRAM_CPU_TRACER: the mesh's bounding box, min then max (Mesh::bounds, PathTracer.cpp:1180-1189)
+    float cpu_max_t;                    // PT_PROGRAM_CPU_TRACER: far - near, the camera ray's maxt (PathTracer.cpp:745)
+    uint32_t cpu_seed;                  // PT_PROGRAM_CPU_TRACER: seed of the counter-based generator
     const float* verify_tris;           // self-check only: the records of ALL triangles in index order (never compacted)
     unsigned long long* verify_out;     // self-check only: [0] queries compared, [1] ids differing, [2] distances differing
     int32_t verify_bounces;             // self-check only: generations of bounce rays compared after the camera rays

@@ -1324,6 +1324,159 @@ __global__ __launch_bounds__(64, PT_DECOUPLED_MIN_WAVES) void pt_render_decouple
     }
 }
 
+// ---- the reference's CPU tracer (PT_PROGRAM_CPU_TRACER) ---------------------------------------------------------------------
+// Scene::color (PathTracer.cpp:932-1052) with scatter (:830-852), Sphere::hit (:595-640), Mesh::hit (:562-586: bounding box
+// test, then every triangle in order), HitRecord::hit (:101-152) and Camera::generateRay (:742-745, through the pixel's
+// corner): spheres AND mesh in one scene, Lambert bounce N + randomUnitVector() from the hit point, the other material types
+// pass the ray on unchanged, sky (1-t) + (1, 0.7, 0.5) t, running SUM per pixel. The reference draws its random numbers from
+// one serial libc rand() stream; here they come from a counter-based generator keyed by (seed, pixel, sample), so pixels and
+// samples are independent. float3's sums run left to right (:61), unlike the shader's.
+__device__ __forceinline__ float dotc(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ v3 normalizec(v3 a) { return a * (1.0f / __builtin_sqrtf((a.x * a.x + a.y * a.y) + a.z * a.z)); }
+__device__ __forceinline__ uint32_t pcg_hash(uint32_t x) {
+    const uint32_t state = x * 747796405u + 2891336453u;
+    const uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+struct CtrRng {
+    uint32_t key, draw;
+    // nextFloat(0, 1), PathTracer.cpp:765-768: (float)rand() / (float)RAND_MAX with a 31-bit value
+    __device__ __forceinline__ float next() {
+        const uint32_t h = pcg_hash(key + pcg_hash(draw++));
+        return (float)(h >> 1) / 2147483648.0f;
+    }
+};
+
+__global__ __launch_bounds__(64) void pt_cpu_tracer_kernel(const PtKernelParams p) {
+    int x, y;
+    const bool mine = pixel_of_lane(p, (int)blockIdx.x, x, y);
+    const size_t pix = mine ? (size_t)y * p.width + x : 0;
+    const v3 pos = V(p.ro[0], p.ro[1], p.ro[2]), llc = V(p.llc[0], p.llc[1], p.llc[2]);
+    const v3 hor = V(p.hor[0], p.hor[1], p.hor[2]), ver = V(p.ver[0], p.ver[1], p.ver[2]);
+    const float fx = (float)x / (float)p.width, fy = (float)y / (float)p.height;
+    const v3 dir0 = normalizec(((llc + hor * fx) + ver * fy) - pos);
+    const float4 prev = reinterpret_cast<const float4*>(p.src)[pix];
+    float sr = prev.x, sg = prev.y, sb = prev.z;
+    const float4* __restrict__ spheres = reinterpret_cast<const float4*>(p.raw_spheres);
+    const float4* __restrict__ mats = reinterpret_cast<const float4*>(p.materials);
+    const float4* __restrict__ recs = reinterpret_cast<const float4*>(p.tris_abs);
+    unsigned rays = 0;
+    for (int s = 0; mine && s < p.num_samples; ++s) {
+        CtrRng rng;
+        rng.key = pcg_hash(p.cpu_seed + pcg_hash((uint32_t)(y * p.width + x))) + pcg_hash(0x9E3779B9u * (uint32_t)(p.first_sample + s * p.sample_stride));
+        rng.draw = 0;
+        v3 ro = pos, rd = dir0;
+        float mint = 0.0f, maxt = p.cpu_max_t;
+        v3 energy = V(1.0f, 1.0f, 1.0f);
+        for (int level = 0; level < p.depth; ++level) {
+            ++rays;
+            v3 rec_point = V(0.f, 0.f, 0.f), rec_normal = V(0.f, 0.f, 0.f);
+            float rec_t = 0.0f;
+            int hit_index = -1;
+            for (int i = 0; i < 10; ++i) {
+                const float4 sp = spheres[i];
+                const v3 c = V(sp.x, sp.y, sp.z);
+                const v3 to = ro - c;
+                const float A = dotc(rd, rd), B = dotc(to, rd), C = dotc(to, to) - sp.w * sp.w;
+                const float disc = B * B - A * C;
+                if (disc > 0.0f) {
+                    const float root = __builtin_sqrtf(disc);
+                    float temp = (-B - root) / A;
+                    bool ok = temp < maxt && temp > mint;
+                    if (!ok) {
+                        temp = (-B + root) / A;
+                        ok = temp < maxt && temp > mint;
+                    }
+                    if (ok) {
+                        rec_point = ro + rd * temp;
+                        rec_normal = (rec_point - c) * (1.0f / sp.w);
+                        rec_t = temp;
+                        maxt = temp;
+                        hit_index = i;
+                    }
+                }
+            }
+            if (p.num_triangles > 0) {
+                // AABB::test with the ray as it stands (Mesh::hit works on a copy of it)
+                float tmin = mint, tmax = maxt;
+                bool inside = true;
+                const float o3[3] = {ro.x, ro.y, ro.z}, d3[3] = {rd.x, rd.y, rd.z};
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    if (!inside) break;
+                    if (__builtin_fabsf(d3[k]) < 0.001f) {
+                        if (o3[k] < p.cpu_bounds[k] || o3[k] > p.cpu_bounds[3 + k]) inside = false;
+                    } else {
+                        const float ood = 1.0f / d3[k];
+                        float t1 = (p.cpu_bounds[k] - o3[k]) * ood, t2 = (p.cpu_bounds[3 + k] - o3[k]) * ood;
+                        if (t1 > t2) { const float sw = t1; t1 = t2; t2 = sw; }
+                        if (t1 > tmin) tmin = t1;
+                        if (t2 < tmax) tmax = t2;
+                        if (tmin > tmax) inside = false;
+                    }
+                }
+                if (inside) {
+                    float best = maxt, bu = 0.f, bv = 0.f, bood = 0.f;
+                    int bid = -1;
+                    for (int i = 0; i < p.num_triangles; ++i) {
+                        const float4 ra = recs[4 * (size_t)i], rb = recs[4 * (size_t)i + 1], rc = recs[4 * (size_t)i + 2];
+                        const v3 a = V(ra.x, ra.y, ra.z), e1 = V(ra.w, rb.x, rb.y), e2 = V(rb.z, rb.w, rc.x);
+                        const v3 q = cross3(rd, e2);
+                        const float det = dotc(e1, q);
+                        if (det < 0.0001f) continue;
+                        const v3 ap = ro - a;
+                        const float u = dotc(ap, q);
+                        if (u < 0.0f || u > det) continue;
+                        const v3 r = cross3(ap, e1);
+                        const float v = dotc(rd, r);
+                        if (v < 0.0f || (u + v) > det) continue;
+                        const float ood = 1.0f / det;
+                        const float temp = dotc(e2, r) * ood;
+                        if (temp > mint && temp < best) { best = temp; bu = u; bv = v; bood = ood; bid = i; }
+                    }
+                    if (bid >= 0) {
+                        // point, barycentrics and normal of the accepted triangle (PathTracer.cpp:139-146)
+                        const float* __restrict__ nn = p.vnormals + (size_t)bid * 9;
+                        const float uy = bu * bood, uz = bv * bood, ux = (1.0f - uy) - uz;
+                        rec_t = best;
+                        rec_point = ro + rd * best;
+                        rec_normal = normalizec((V(nn[0], nn[1], nn[2]) * ux + V(nn[3], nn[4], nn[5]) * uy) + V(nn[6], nn[7], nn[8]) * uz);
+                        maxt = best;
+                        hit_index = 0;   // the mesh takes the first material (PathTracer.cpp:975)
+                    }
+                }
+            }
+            if (hit_index < 0) break;
+            const float4 m = mats[hit_index];
+            v3 attenuation = V(1.0f, 1.0f, 1.0f);
+            // scatter(), PathTracer.cpp:830-852
+            ro = rec_point + rec_normal * 0.001f;
+            mint = 0.0f;
+            maxt = 3.402823466e+38f;
+            if (m.w == 0.0f) {  // Material::LAMBERT; the other types leave the direction as it is (their code is commented out)
+                const float z = rng.next() * 2.0f - 1.0f;
+                const float a = (rng.next() * 2.0f) * 3.14159274f;
+                const float r = __builtin_sqrtf(1.0f - z * z);
+                rd = normalizec(rec_normal + V(lp_sincos<true>(a) * r, lp_sincos<false>(a) * r, z));
+                attenuation = V(m.x, m.y, m.z);
+            }
+            energy = V(energy.x * attenuation.x, energy.y * attenuation.y, energy.z * attenuation.z);
+            if ((energy.x + energy.y) + energy.z == 0.0f) break;
+        }
+        const float t = 0.5f * (rd.y + 1.0f);
+        sr += energy.x * ((1.0f - t) + 1.0f * t);
+        sg += energy.y * ((1.0f - t) + 0.7f * t);
+        sb += energy.z * ((1.0f - t) + 0.5f * t);
+    }
+    if (mine) reinterpret_cast<float4*>(p.dst)[pix] = make_float4(sr, sg, sb, prev.w + (float)p.num_samples);
+    const unsigned long long wave_rays = wave_sum(rays);
+    if ((threadIdx.x & 63) == 0 && wave_rays) {
+        unsigned long long* counters = p.counters + (size_t)(blockIdx.x % PT_COUNTER_SLOTS) * PT_COUNTER_STRIDE;
+        atomicAdd(&counters[0], wave_rays);
+        atomicAdd(&counters[4], wave_rays);
+    }
+}
+
 template <int KIND>
 __global__ __launch_bounds__(PT_TILE_THREADS) void pt_primary_kernel(const PtKernelParams p) {
     __shared__ uint32_t s_stack[KIND == 2 ? PT_TILE_WAVES : 1][KIND == 2 ? PT_BVH_STACK : 1];
@@ -1809,6 +1962,11 @@ hipError_t pt_launch_schedule_items(const uint32_t* tile_cost, PtWorkItem* items
 hipError_t pt_launch_render(const PtKernelParams& p, int program_kind, hipStream_t stream) {
     if (p.win_w <= 0 || p.win_h <= 0 || p.num_samples <= 0) return hipSuccess;
     const dim3 grid(p.items ? p.max_items : window_tiles(p)), block(PT_TILE_THREADS);
+    if (program_kind == 2) {
+        if (PT_TILE_WAVES != 1 || p.items) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(pt_cpu_tracer_kernel, dim3(window_tiles(p)), dim3(64), 0, stream, p);
+        return hipGetLastError();
+    }
     if (program_kind == 0) hipLaunchKernelGGL((pt_render_kernel<0, false>), grid, block, 0, stream, p);
     else if (p.shading_mode != 0) {
         // lane_walk: 1 = lanes decoupled (default), 2 = the per-lane walk with all lanes in step, 0 = one walk per wave

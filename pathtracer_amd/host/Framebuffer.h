@@ -68,4 +68,27 @@ struct Framebuffer {
             out[i].fromLinear(b, g, r);
         }
     }
+
+    // For PT_PROGRAM_CPU_TRACER, whose target holds running SUMS like the reference's CPU path: stores a width*height RGBA32F
+    // image of sums after `samples` frames exactly where that path keeps things (PathTracer.cpp:1319-1368). The frame loop
+    // walks 16x16 tiles (th, tw, then rows j, then pixels i) and advances ONE pointer through accumulationBuffer, so
+    // accumulationBuffer is in tile-traversal order: entry k belongs to the k-th pixel visited. colorBuffer is in pixel order
+    // (row j + 16 th, column i + 16 tw) and receives fromLinear(z, y, x) of sum / samples. Pixels outside the whole tiles are
+    // never visited by the reference (width / 16 and height / 16 round down) and stay as they are.
+    void storeSumsTileOrder(const float* rgba_sums, int samples) {
+        const int tile = 16, tiles_w = width / tile, tiles_h = height / tile;
+        Color* out = reinterpret_cast<Color*>(colorBuffer);
+        const float inv = 1.f / static_cast<float>(samples);
+        float* accum = accumulationBuffer;
+        for (int th = 0; th < tiles_h; ++th)
+            for (int tw = 0; tw < tiles_w; ++tw)
+                for (int j = 0; j < tile; ++j)
+                    for (int i = 0; i < tile; ++i) {
+                        const size_t pix = static_cast<size_t>(width) * (tile * th + j) + (tile * tw + i);
+                        const float x = rgba_sums[4 * pix], y = rgba_sums[4 * pix + 1], z = rgba_sums[4 * pix + 2];
+                        accum[0] = x; accum[1] = y; accum[2] = z;
+                        accum += 3;
+                        out[pix].fromLinear(z * inv, y * inv, x * inv);
+                    }
+    }
 };

@@ -90,6 +90,14 @@ int RunRenderLoop(const RenderOptions& opt, Framebuffer& fb, RenderResult& resul
 
     // program (PathTracer.cpp:1248-1251)
     Shader pathTracingShader;
+    const bool cpu_tracer = opt.program_kind == 2;   // the branch the reference compiles without USE_GLSL (PathTracer.cpp:1317-1368)
+    uint32_t cpu_program = 0;
+    if (cpu_tracer) {
+        PT_CHECK(pt_program_create(ctx, PT_PROGRAM_CPU_TRACER, &cpu_program));
+        PT_CHECK(pt_set_cpu_tracer(ctx, opt.seed, 100.f - 0.1f));   // srand (PathTracer.cpp:1216); far - near (:1161, 745)
+        PT_CHECK(pt_set_accum_mode(ctx, PT_ACCUM_SUM));             // Framebuffer::accumulationBuffer starts at zero (Framebuffer.h:51-52)
+        PT_CHECK(pt_target_clear(ctx));
+    } else {
     pathTracingShader.loadVertexShader((opt.shader_dir + "/postprocess.vs").c_str());
     if (opt.program_kind >= 0) {
         // explicit choice: do not look at the shader file
@@ -102,6 +110,8 @@ int RunRenderLoop(const RenderOptions& opt, Framebuffer& fb, RenderResult& resul
         result.error = "could not create the path-tracing program";
         return 1;
     }
+    }
+    const uint32_t program = cpu_tracer ? cpu_program : pathTracingShader.getProgram();
 
     // uploads (PathTracer.cpp:1253-1288)
     PT_CHECK(pt_upload_spheres(ctx, &scene.spheres[0].center.x, (int32_t)scene.spheres.size()));
@@ -130,7 +140,7 @@ int RunRenderLoop(const RenderOptions& opt, Framebuffer& fb, RenderResult& resul
         const auto t1 = std::chrono::steady_clock::now();
 
         // PathTracer.cpp:1370-1403
-        PT_CHECK(pt_use_program(ctx, pathTracingShader.getProgram()));
+        PT_CHECK(pt_use_program(ctx, program));
         PtUniforms u;
         const Camera& cam = scene.camera;
         const float3* src[4] = {&cam.position, &cam.lowerLeftCorner, &cam.horizontal, &cam.vertical};
@@ -162,12 +172,14 @@ int RunRenderLoop(const RenderOptions& opt, Framebuffer& fb, RenderResult& resul
 
     std::vector<float> rgba(static_cast<size_t>(width) * height * 4);
     PT_CHECK(pt_readback_rgba32f(ctx, rgba.data()));
-    fb.storeMean(rgba.data(), samples);
+    if (cpu_tracer) fb.storeSumsTileOrder(rgba.data(), samples);
+    else fb.storeMean(rgba.data(), samples);
     if (!opt.output_tga.empty() && !WriteTga(opt.output_tga.c_str(), fb)) {
         result.error = "cannot write " + opt.output_tga;
         return 1;
     }
-    pathTracingShader.destroyProgram();
+    if (cpu_tracer) PT_CHECK(pt_program_destroy(ctx, cpu_program));
+    else pathTracingShader.destroyProgram();
     return 0;
 #undef PT_CHECK
 }

@@ -19,7 +19,9 @@ struct RenderOptions {
     int passes = 16;                                 // frames to render
     int samples_per_dispatch = 1;                    // 1 = one dispatch per frame, exactly like the reference
     int device = 0;
-    int program_kind = -1;                           // -1 = decide from the shader file / default; 0 world; 1 mesh
+    int program_kind = -1;                           // -1 = decide from the shader file / default; 0 world; 1 mesh; 2 = the reference's CPU
+                                                     // tracer (Scene::color), running sums kept as Framebuffer::accumulationBuffer keeps them
+    uint32_t seed = 18;                              // CPU tracer only: the reference seeds with srand(2 ^ 17 - 1) = srand(18) (PathTracer.cpp:1216)
     bool quiet = false;                              // suppress the per-frame line
     std::string output_tga;                          // optional: write the display image when done
     // optional camera override (eye, target, fov); the reference hard-codes eye 0, target +z, fov 60
