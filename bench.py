@@ -113,7 +113,7 @@ def which_kernel(st, program, shading):
         return "pt_render_kernel<0,false>", "spheres"
     if shading == "materials":
         if st["grid_triangle_tests"] > 0:
-            return "pt_render_kernel<5,true>", "lane_walk"
+            return "pt_render_decoupled_kernel", "lane_walk"
         if st["bvh_node_fetches"] > 0:
             return "pt_render_kernel<2,true>", "wave_walk"
         return "pt_render_kernel<1,true>", "loop_from"

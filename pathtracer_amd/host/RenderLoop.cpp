@@ -124,7 +124,7 @@ int RunRenderLoop(const RenderOptions& opt, Framebuffer& fb, RenderResult& resul
         const std::vector<int32_t> ids = resolveMaterialIds(mesh, table.size());
         PT_CHECK(pt_upload_materials(ctx, &table[0].r, (int32_t)table.size()));
         PT_CHECK(pt_upload_material_ids(ctx, ids.data(), (int32_t)ids.size()));
-        PT_CHECK(pt_set_shading_mode(ctx, PT_SHADE_MATERIALS));
+        PT_CHECK(pt_set_shading_mode(ctx, opt.lambert_unit_form ? PT_SHADE_MATERIALS_UNIT : PT_SHADE_MATERIALS));
     }
     if (opt.accel == 1) PT_CHECK(pt_build_accel(ctx));
     PT_CHECK(pt_enable_timing(ctx, 1));

@@ -29,6 +29,7 @@ struct RenderOptions {
     float eye[3] = {0, 0, 0}, target[3] = {0, 0, 1}, up[3] = {0, 1, 0}, fov = 60.f;
     float translate_z = 3.f;                         // PathTracer.cpp:1179
     bool shade_materials = false;                    // true: PT_SHADE_MATERIALS with the table built from the MTL file
+    bool lambert_unit_form = false;                  // with shade_materials: PT_SHADE_MATERIALS_UNIT, the bounce of pathtracing.fs:272
     bool file_normals = false;                       // true: normals through the OBJ's normal indices instead of the reference's pairing
     int accel = 1;                                   // 1 = pt_build_accel (direction grid / LBVH, same image); 0 = the shader's plain loop
 };

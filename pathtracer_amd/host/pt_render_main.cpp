@@ -1,6 +1,6 @@
 // Command-line front end of the render loop: the headless counterpart of the reference executable.
 //   pt_render [--obj file.obj] [--mtl-dir dir/] [--size WxH] [--passes N] [--batch N] [--kind world|mesh|cpu]
-//             [--device N] [--out image.tga] [--quiet] [--shading reference|materials] [--accel auto|loop]
+//             [--device N] [--out image.tga] [--quiet] [--shading reference|materials|materials_unit] [--accel auto|loop]
 //             [--translate-z Z] [--camera ex,ey,ez,tx,ty,tz,fov] [--file-normals]
 #include <cstdio>
 #include <cstdlib>
@@ -24,7 +24,7 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--depth")) opt.depth = atoi(next("--depth"));
         else if (!strcmp(argv[i], "--device")) opt.device = atoi(next("--device"));
         else if (!strcmp(argv[i], "--kind")) { const char* k = next("--kind"); opt.program_kind = !strcmp(k, "mesh") ? 1 : (!strcmp(k, "cpu") ? 2 : 0); }
-        else if (!strcmp(argv[i], "--shading")) opt.shade_materials = !strcmp(next("--shading"), "materials");
+        else if (!strcmp(argv[i], "--shading")) { const char* m = next("--shading"); opt.lambert_unit_form = !strcmp(m, "materials_unit"); opt.shade_materials = opt.lambert_unit_form || !strcmp(m, "materials"); }
         else if (!strcmp(argv[i], "--accel")) opt.accel = !strcmp(next("--accel"), "loop") ? 0 : 1;
         else if (!strcmp(argv[i], "--file-normals")) opt.file_normals = true;
         else if (!strcmp(argv[i], "--translate-z")) opt.translate_z = (float)atof(next("--translate-z"));

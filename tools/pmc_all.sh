@@ -7,5 +7,5 @@ run instanced_grid --workload instanced --spp 64 --steps 10        # <4,false> o
 run suzanne_bvh --workload suzanne --accel bvh --steps 10          # <2,false>: per-wave LBVH walk
 run cornell_loop --accel brute --steps 10                          # <1,false>: the shader's own loop
 run cornell_materials --shading materials --steps 6                # <1,true>: diffuse/emissive, all-triangles loop
-run instanced_materials --workload instanced --shading materials --spp 16 --steps 6   # <5,true>: per-lane LBVH walk
-run suzanne_materials --workload suzanne --shading materials --spp 64 --steps 6       # <5,true> on a mesh that fits the L2
+run instanced_materials --workload instanced --shading materials --spp 16 --steps 6   # pt_render_decoupled_kernel: per-lane LBVH walk, lanes decoupled
+run suzanne_materials --workload suzanne --shading materials --spp 64 --steps 6       # pt_render_decoupled_kernel on a mesh that fits the L2

@@ -40,7 +40,7 @@ PASSES = {
 
 
 def short_name(kernel_name):
-    m = re.search(r"pt_render_kernel<[^>]*>", kernel_name)
+    m = re.search(r"pt_render_kernel<[^>]*>|pt_render_decoupled_kernel|pt_cpu_tracer_kernel", kernel_name)
     return m.group(0).replace(" ", "") if m else kernel_name
 
 
@@ -67,10 +67,10 @@ def collect(tag, bench_args):
         # kernel variant that was dispatched most often, and of its dispatches the last `steps` (the timed ones)
         by_kernel = {}
         for r_ in rows:
-            if "pt_render_kernel" in r_["Kernel_Name"]:
+            if "pt_render_" in r_["Kernel_Name"] or "pt_cpu_tracer_kernel" in r_["Kernel_Name"]:
                 by_kernel.setdefault(r_["Kernel_Name"], set()).add(int(r_["Dispatch_Id"]))
         if not by_kernel:
-            print(f"pass {name}: no pt_render_kernel dispatch in the counter file", file=sys.stderr)
+            print(f"pass {name}: no render kernel dispatch in the counter file", file=sys.stderr)
             sys.exit(1)
         kernel_name = max(by_kernel, key=lambda k: len(by_kernel[k]))
         timed = sorted(by_kernel[kernel_name])[-a.steps:]
