@@ -128,7 +128,7 @@ def roofline(st, kernel_ms, scene, shading, pmc, pmc_note):
     """The render kernel against the ceiling that bounds it, from the work it executed in the timed launches."""
     n = max(1, st["dispatches"])
     per = {k: st[k] / n for k in ("rays", "rays_traced", "samples", "lane_slots", "bvh_node_fetches", "bvh_triangle_fetches",
-                                  "grid_triangle_tests", "shaded_hits", "loop_triangle_visits", "loop_full_tests")}
+                                  "grid_triangle_tests", "shaded_hits", "loop_triangle_visits", "loop_full_tests", "lane_walk_records")}
     kernel, kind = which_kernel(st, scene.program, shading)
     sec = kernel_ms * 1e-3
     lane_util = per["rays_traced"] / per["lane_slots"] if per["lane_slots"] else 0.0
@@ -136,18 +136,24 @@ def roofline(st, kernel_ms, scene, shading, pmc, pmc_note):
            "events_per_launch": {k: v for k, v in per.items() if v}}
     brute = per["rays_traced"] * FLOP_PER_TRI_TEST_SHADER * scene.num_triangles
     if kind in ("wave_walk", "lane_walk"):
-        # dependent record fetches: 64-byte node and triangle records. Per-wave walk: one scalar fetch serves the wave;
-        # per-lane walk: every lane gathers its own.
-        recs = per["grid_triangle_tests"] if kind == "lane_walk" else per["bvh_node_fetches"] + per["bvh_triangle_fetches"]
-        nbytes = recs * 64.0
-        footprint = scene.num_triangles * 128     # node + triangle record per triangle
+        # dependent record fetches. Per-wave walk: 64-byte node and triangle records, one scalar fetch serves the wave; per-lane
+        # walk: every lane gathers its own 64-byte four-child nodes and 48-byte triangle records.
+        if kind == "lane_walk":
+            recs = per["grid_triangle_tests"]
+            nbytes = (recs - per["lane_walk_records"]) * 64.0 + per["lane_walk_records"] * 48.0
+            footprint = scene.num_triangles * (48 + 32)   # a record per triangle, about a node per two triangles
+        else:
+            recs = per["bvh_node_fetches"] + per["bvh_triangle_fetches"]
+            nbytes = recs * 64.0
+            footprint = scene.num_triangles * 128     # node + triangle record per triangle
         level, _, peak = next(g for g in GATHER_PEAK if footprint <= g[1])
         gbs = nbytes / sec * 1e-9 if sec > 0 else 0.0
         out.update({"bound": level if level != "hbm" else "hbm", "achieved": gbs, "peak": peak, "unit": "GB/s", "frac": gbs / peak,
                     "hbm_peak": 8000.0, "frac_of_hbm_peak": gbs / 8000.0,
                     "algorithmic_bytes_per_launch": nbytes, "records_footprint_bytes": footprint,
                     "records_per_evaluated_query": recs / per["rays_traced"] if per["rays_traced"] else 0.0,
-                    "note": "bytes = 64-byte node and triangle records fetched by the hierarchy walk (counted in-kernel: "
+                    "note": "bytes = " + ("64-byte four-child nodes and 48-byte triangle records" if kind == "lane_walk" else "64-byte node and triangle records")
+                            + " fetched by the hierarchy walk (counted in-kernel: "
                             + ("per lane" if kind == "lane_walk" else "once per wave, scalar fetches") +
                             "), priced against the random-row gather rate of the level their footprint fits "
                             "(MI355X_MICROARCH.md: L2 16.8, Infinity Cache 8.6, HBM 8.0 TB/s)"})

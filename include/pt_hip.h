@@ -133,6 +133,8 @@ typedef struct PtStats {
                                   of the wave tests its ray against each) */
     uint64_t loop_full_tests;  /* all-triangles loop, measurement builds (-DPT_V_COUNT_FULL) only: of those visits, the ones that
                                   went past the wave-uniform back-face skip; 0 in the product build */
+    uint64_t lane_walk_records; /* per-lane hierarchy walk (PT_SHADE_MATERIALS): of the records counted in grid_triangle_tests, the
+                                  triangle records (48 bytes each in the compact form; the others are 32-byte nodes) */
     uint32_t dispatches;       /* pt_dispatch calls */
     float last_dispatch_ms;    /* device time of the most recent pt_dispatch (scheduler, render and fold kernels);
                                   0 unless timing is enabled */

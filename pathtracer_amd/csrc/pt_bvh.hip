@@ -141,10 +141,10 @@ __global__ __launch_bounds__(256) void bvh_refit_pass(const uint32_t* __restrict
 
 // Reference to a child as the traversal sees it: subtrees of at most PT_BVH_LEAF_MAX triangles are leaves
 // (0x80000000 | first << 3 | count-1, sorted positions), everything else an internal node index.
-__device__ __forceinline__ uint32_t traversal_ref(int ref, const int* __restrict__ range) {
+__device__ __forceinline__ uint32_t traversal_ref(int ref, const int* __restrict__ range, int leaf_max = PT_BVH_LEAF_MAX) {
     if (ref < 0) return 0x80000000u | ((uint32_t)(~ref) << 3);
     const int first = range[2 * ref], count = range[2 * ref + 1] - first + 1;
-    if (count <= PT_BVH_LEAF_MAX) return 0x80000000u | ((uint32_t)first << 3) | (uint32_t)(count - 1);
+    if (count <= leaf_max) return 0x80000000u | ((uint32_t)first << 3) | (uint32_t)(count - 1);
     return (uint32_t)ref;
 }
 
@@ -204,15 +204,119 @@ __global__ __launch_bounds__(256) void bvh_gather_records(const uint32_t* __rest
     }
 }
 
+// Frame of the 16-bit boxes: around the root's box, wider than any padded child box can reach (a pad is at most 1.5e-5 of the
+// largest coordinate), 65533 steps across so that the outward rounding below never leaves 0..65535.
+__global__ void bvh_emit_qframe(const float* __restrict__ node_box, float scene_scale, float* __restrict__ qframe) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int k = 0; k < 3; ++k) {
+        const float margin = 2.0e-5f * scene_scale + 1.0e-20f;
+        const float base = node_box[k] - margin;
+        const float extent = (node_box[3 + k] + margin) - base;
+        qframe[k] = base;
+        qframe[3 + k] = extent / 65533.0f;
+    }
+    qframe[6] = 0.f;
+    qframe[7] = 0.f;
+}
+
+// ---- wide nodes --------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bvh_parents(const int* __restrict__ child, int n, int* __restrict__ parent) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    if (i == 0) parent[0] = -1;
+    for (int c = 0; c < 2; ++c) {
+        const int ref = child[2 * i + c];
+        if (ref >= 0) parent[ref] = i;
+    }
+}
+
+// flag[i] = 1 when binary node i becomes a wide node: an even number of ancestors, and more triangles below it than a leaf holds
+__global__ __launch_bounds__(256) void bvh_wide_flags(const int* __restrict__ parent, const int* __restrict__ range, int n, int* __restrict__ flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    int depth = 0;
+    for (int j = parent[i]; j >= 0; j = parent[j]) ++depth;
+    flag[i] = ((depth & 1) == 0 && range[2 * i + 1] - range[2 * i] + 1 > PT_BVH_WIDE_LEAF_MAX) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void bvh_wide_indices(const int* __restrict__ flag, int n, int* __restrict__ wide_index) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    if (!flag[i]) wide_index[i] = -1;  // (flagged entries hold the exclusive sum = their index)
+}
+
+// Wide node of binary node i: the children of i, an internal child (more triangles than a leaf holds) replaced by ITS two
+// children. Boxes are the ones bvh_emit_nodes pads (same pads, absolute coordinates), rounded outwards to the frame's steps and
+// one step further. A walk decodes a bound as fma(q, step / d, (base - o) / d): its rounding is some 1e-7 of the scene's size in
+// position, a step is 1.5e-5 of it.
+__global__ __launch_bounds__(256) void bvh_emit_wide(const uint32_t* __restrict__ order, const int* __restrict__ child,
+                                                     const int* __restrict__ range, const float* __restrict__ tri_box,
+                                                     const float* __restrict__ node_box, const int* __restrict__ wide_index, int n,
+                                                     float extra_pad, const float* __restrict__ qframe, uint32_t* __restrict__ nodes_w) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1 || wide_index[i] < 0) return;
+    uint32_t* out = nodes_w + (size_t)wide_index[i] * PT_BVH_WNODE_WORDS;
+    int slot = 0;
+    auto put = [&](int ref) {
+        const float* box = ref < 0 ? tri_box + 6 * (size_t)order[~ref] : node_box + 6 * (size_t)ref;
+        float far = 0.f;
+        for (int k = 0; k < 6; ++k) far = fmaxf(far, fabsf(box[k]));
+        const float pad = 1.1e-5f * far + extra_pad + 1.0e-30f;
+        for (int k = 0; k < 3; ++k) {
+            const float lo = (box[k] - pad) - qframe[k], hi = (box[3 + k] + pad) - qframe[k];
+            const float qlo = floorf(lo / qframe[3 + k]) - 1.0f, qhi = ceilf(hi / qframe[3 + k]) + 1.0f;
+            const uint32_t ulo = (uint32_t)fminf(fmaxf(qlo, 0.0f), 65535.0f), uhi = (uint32_t)fminf(fmaxf(qhi, 0.0f), 65535.0f);
+            out[4 * slot + k] = ulo | (uhi << 16);
+        }
+        const uint32_t t = traversal_ref(ref, range, PT_BVH_WIDE_LEAF_MAX);
+        out[4 * slot + 3] = (t & 0x80000000u) ? t : (uint32_t)wide_index[ref];
+        ++slot;
+    };
+    for (int c = 0; c < 2; ++c) {
+        const int ref = child[2 * i + c];
+        if (traversal_ref(ref, range, PT_BVH_WIDE_LEAF_MAX) & 0x80000000u) {
+            put(ref);
+        } else {  // an internal node of an odd level: its children stand in for it
+            put(child[2 * ref]);
+            put(child[2 * ref + 1]);
+        }
+    }
+    for (; slot < 4; ++slot) {
+        out[4 * slot] = 0u; out[4 * slot + 1] = 0u; out[4 * slot + 2] = 0u;
+        out[4 * slot + 3] = PT_BVH_NO_CHILD;
+    }
+}
+
+// a, e1, e2 and the id of the triangle at each sorted position, 48 bytes; zero records after the last
+__global__ __launch_bounds__(256) void bvh_gather_qrecords(const uint32_t* __restrict__ order, const float4* __restrict__ tris_abs, int n,
+                                                           float4* __restrict__ tris_q) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n + PT_TRI_PAD) return;
+    float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
+    if (k < n) {
+        const uint32_t id = order[k];
+        q0 = tris_abs[4 * (size_t)id];
+        q1 = tris_abs[4 * (size_t)id + 1];
+        q2 = tris_abs[4 * (size_t)id + 2];
+        q2.y = __uint_as_float(id);
+        q2.z = 0.f;
+        q2.w = 0.f;
+    }
+    tris_q[3 * (size_t)k] = q0;
+    tris_q[3 * (size_t)k + 1] = q1;
+    tris_q[3 * (size_t)k + 2] = q2;
+}
+
 inline dim3 grid_for(int n) { return dim3((unsigned)((n + 255) / 256)); }
 
 }  // namespace
 
 size_t pt_bvh_sort_temp_bytes(int32_t n) {
-    size_t bytes = 0;
+    size_t bytes = 0, scan = 0;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
                                              (const uint32_t*)nullptr, (uint32_t*)nullptr, n, 0, 63, nullptr);
-    return bytes;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan, (const int*)nullptr, (int*)nullptr, n, nullptr);  // numbering of the wide nodes
+    return bytes > scan ? bytes : scan;
 }
 
 hipError_t pt_bvh_build_topology(const PtBvhBuild& b, hipStream_t stream, int32_t* out_passes) {
@@ -244,6 +348,13 @@ hipError_t pt_bvh_build_topology(const PtBvhBuild& b, hipStream_t stream, int32_
         if (e != hipSuccess) return e;
     }
     if (out_passes) *out_passes = pass - 1;
+    // numbering of the wide nodes (every second level)
+    hipLaunchKernelGGL(bvh_parents, grid_for(n - 1), dim3(256), 0, stream, b.child, n, b.parent);
+    hipLaunchKernelGGL(bvh_wide_flags, grid_for(n - 1), dim3(256), 0, stream, b.parent, b.range, n, b.wide_flag);
+    bytes = b.sort_tmp_bytes;
+    e = hipcub::DeviceScan::ExclusiveSum(b.sort_tmp, bytes, b.wide_flag, b.wide_index, n - 1, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(bvh_wide_indices, grid_for(n - 1), dim3(256), 0, stream, b.wide_flag, n, b.wide_index);
     return hipGetLastError();
 }
 
@@ -257,7 +368,12 @@ hipError_t pt_bvh_emit(const PtBvhBuild& b, const float ro[3], const float* tris
         // larger of box and origin coordinates, so the pad also carries a term of the scene's size.
         hipLaunchKernelGGL(bvh_emit_nodes, grid_for(n - 1), dim3(256), 0, stream, b.order, b.child, b.range, b.tri_box, b.node_box, n, 0.0f,
                            0.0f, 0.0f, 4.0e-6f * b.scene_scale, b.nodes_abs);
+        hipLaunchKernelGGL(bvh_emit_qframe, dim3(1), dim3(64), 0, stream, b.node_box, b.scene_scale, b.qframe);
+        hipLaunchKernelGGL(bvh_emit_wide, grid_for(n - 1), dim3(256), 0, stream, b.order, b.child, b.range, b.tri_box, b.node_box, b.wide_index, n,
+                           4.0e-6f * b.scene_scale, b.qframe, b.nodes_w);
     }
+    hipLaunchKernelGGL(bvh_gather_qrecords, grid_for(n + PT_TRI_PAD), dim3(256), 0, stream, b.order, reinterpret_cast<const float4*>(tris_abs), n,
+                       reinterpret_cast<float4*>(b.tris_q));
     hipLaunchKernelGGL(bvh_gather_records, grid_for(n + PT_TRI_PAD), dim3(256), 0, stream, b.order, reinterpret_cast<const float4*>(tris_abs), n,
                        reinterpret_cast<float4*>(b.sorted_tris_abs), b.sorted_ids, false);
     hipLaunchKernelGGL(bvh_gather_records, grid_for(n + PT_TRI_PAD), dim3(256), 0, stream, b.order, reinterpret_cast<const float4*>(tris), n,

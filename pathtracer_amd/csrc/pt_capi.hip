@@ -257,7 +257,7 @@ void free_target(PtContext* ctx) {
 void free_bvh(PtContext* ctx) {
     PtBvhBuild& b = ctx->bvh;
     void* ptrs[] = {b.tri_box, b.scene_box, b.keys_tmp, b.keys, b.order_tmp, b.order, b.sort_tmp, b.child, b.range, b.node_box, b.done, b.remaining,
-                    b.nodes, b.sorted_tris, b.sorted_ids, b.nodes_abs, b.sorted_tris_abs};
+                    b.nodes, b.sorted_tris, b.sorted_ids, b.nodes_abs, b.sorted_tris_abs, b.nodes_w, b.tris_q, b.qframe, b.parent, b.wide_index, b.wide_flag};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     b = PtBvhBuild{};
@@ -531,6 +531,9 @@ PtStatus fill_params(PtContext* ctx, PtKernelParams* p, const Program** prog_out
                 p->lane_stack_limit = ctx->lane_stack_limit;
                 p->bvh_nodes_abs = ctx->bvh.nodes_abs;
                 p->bvh_tris_abs = ctx->bvh.sorted_tris_abs;
+                p->bvh_nodes_w = ctx->bvh.nodes_w;
+                p->bvh_tris_q = ctx->bvh.tris_q;
+                p->bvh_qframe = ctx->bvh.qframe;
                 p->bvh_ids = ctx->bvh.sorted_ids;
             }
         } else if (use_bvh) {
@@ -631,6 +634,7 @@ PtStatus pt_create(int32_t device, PtContext** out_ctx) {
     if (sched && sched[0] == '0') ctx->sched_mode = 0;
     else if (sched && sched[0] == 't') ctx->sched_mode = 1;
     ctx->wave_slots = prop.multiProcessorCount * 4 * 8;
+
     if (const char* g = getenv("PT_AUTO_GRID")) ctx->auto_grid = g[0] != '0';
     if (const char* g = getenv("PT_PRIMARY_CACHE")) ctx->primary_cache_enabled = g[0] != '0';
     if (const char* g = getenv("PT_GRID_QUEUE")) ctx->grid_queue_override = atoi(g);
@@ -857,6 +861,12 @@ PtStatus pt_build_accel(PtContext* ctx) {
     alloc(&b.sorted_ids, (nn + PT_TRI_PAD) * sizeof(int));
     alloc(&b.nodes_abs, ni * PT_BVH_NODE_FLOATS * sizeof(float));
     alloc(&b.sorted_tris_abs, (nn + PT_TRI_PAD) * PT_TRI_FLOATS * sizeof(float));
+    alloc(&b.nodes_w, ni * PT_BVH_WNODE_WORDS * sizeof(uint32_t));
+    alloc(&b.parent, ni * sizeof(int));
+    alloc(&b.wide_index, ni * sizeof(int));
+    alloc(&b.wide_flag, ni * sizeof(int));
+    alloc(&b.tris_q, (nn + PT_TRI_PAD) * PT_BVH_QTRI_FLOATS * sizeof(float));
+    alloc(&b.qframe, 8 * sizeof(float));
     if (e == hipSuccess) e = pt_bvh_build_topology(b, ctx->stream, &ctx->bvh_refit_passes);
     if (e != hipSuccess) {
         free_bvh(ctx);
@@ -1051,8 +1061,12 @@ PtStatus dispatch_range(PtContext* ctx, int32_t first_sample, int32_t num_sample
             // 2.6). A view whose work sits in few tiles is different: when the factor-1 list already splits a fifth of
             // the wave slots' worth of tiles, the largest factor is used from then on (968 triangles: 1.19 -> 0.96 ms,
             // 3,936: 2.22 -> 1.94, the sphere scene 0.71 -> 0.65), until the costs are dropped (new view).
+            // The per-lane walk of the materials mode sits between the two (1M triangles at 4K, 16 samples: 12.7 ms at factor 1, 14.0
+            // at 4; 36 triangles through the hierarchy: 7.3 / 8.1; but 3,936 triangles at 1080p: 6.0 / 5.7, 968: 4.0 / 3.5, and
+            // 6.1 / 3.9 at factor 16): factor 1, and 4 for a view found to be concentrated.
             const float base_factor = ctx->split_factor >= 0.f ? std::min(ctx->split_factor, (float)PT_MAX_SPLIT_FACTOR)
-                                                               : ((p.bvh_nodes || p.bvh_nodes_abs) ? 4.0f : 1.0f);
+                                                               : (p.bvh_nodes ? 4.0f : 1.0f);
+            const float eager_factor = p.bvh_nodes_abs ? 4.0f : (float)PT_MAX_SPLIT_FACTOR;
             const bool splitting = ctx->sched_mode == 2 && num_samples > 1;
             const int entry_bytes = is_materials(ctx->shading_mode) && prog->kind != PT_PROGRAM_WORLD ? 16 : 8;  // what a parked sample takes
             const size_t slot_bytes = (size_t)num_samples * PT_TILE_THREADS * (size_t)entry_bytes;
@@ -1061,7 +1075,7 @@ PtStatus dispatch_range(PtContext* ctx, int32_t first_sample, int32_t num_sample
             if (!reuse) {
                 // The scheduler's counts are read back (a short stall, at rebuilds only): they size the launches and the
                 // scratch exactly, and they tell whether this view wants the eager split.
-                float factor = (ctx->concentrated && ctx->split_factor < 0.f) ? (float)PT_MAX_SPLIT_FACTOR : base_factor;
+                float factor = (ctx->concentrated && ctx->split_factor < 0.f) ? eager_factor : base_factor;
                 uint32_t c[2] = {0, 0};
                 for (;;) {
                     const int max_split = splitting ? (int)(factor * (float)ctx->wave_slots) : 0;
@@ -1077,7 +1091,7 @@ PtStatus dispatch_range(PtContext* ctx, int32_t first_sample, int32_t num_sample
                         fprintf(stderr, "[pt sched] %d tiles, %d samples, costs from %lld samples, factor %g: %u items, %u split tiles\n", tiles,
                                 num_samples, (long long)ctx->cost_samples, (double)factor, c[0], c[1]);
                     if (ctx->split_factor < 0.f && factor == 1.0f && c[1] >= (uint32_t)(ctx->wave_slots / 5)) {
-                        factor = (float)PT_MAX_SPLIT_FACTOR;  // work concentrated in few tiles
+                        factor = eager_factor;  // work concentrated in few tiles
                         ctx->concentrated = true;
                         continue;
                     }
@@ -1370,10 +1384,10 @@ PtStatus pt_get_stats(PtContext* ctx, PtStats* out) {
     PT_REQUIRE(slots != nullptr, PT_ERR_HIP, "out of host memory");
     hipError_t ce = hipMemcpyAsync(slots, ctx->d_counters, kCounterBytes, hipMemcpyDeviceToHost, ctx->stream);
     if (ce == hipSuccess) ce = hipStreamSynchronize(ctx->stream);
-    unsigned long long c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long c[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (ce == hipSuccess)
         for (size_t k = 0; k < PT_COUNTER_SLOTS; ++k)
-            for (int j = 0; j < 9; ++j) c[j] += slots[k * PT_COUNTER_STRIDE + j];
+            for (int j = 0; j < 13; ++j) c[j] += slots[k * PT_COUNTER_STRIDE + j];
     delete[] slots;
     PT_HIP_TRY(ce);
     out->rays = c[0];
@@ -1387,6 +1401,10 @@ PtStatus pt_get_stats(PtContext* ctx, PtStats* out) {
     out->shaded_hits = c[6];
     out->loop_triangle_visits = c[7];
     out->loop_full_tests = c[8];
+    out->lane_walk_records = c[9];
+    if (getenv("PT_PRINT_PHASES")) {  // measurement builds (-DPT_V_STATE_COUNT): clock ticks of the wave loop's phases, summed over waves
+        fprintf(stderr, "[pt phases] hand-out %llu shade %llu walk %llu ticks\n", c[10], c[11], c[12]);
+    }
     out->dispatches = ctx->dispatches;
     out->last_dispatch_ms = ctx->last_ms;
     out->total_dispatch_ms = ctx->total_ms;

@@ -30,6 +30,17 @@ struct PtTriRecordLayout {
 //   [12] left ref, [13] right ref (uint bits): 0x80000000 | first << 3 | count-1 = leaf of `count` triangles starting
 //   at sorted position `first`; otherwise the index of an internal node.
 #define PT_BVH_NODE_FLOATS 16
+// Wide, compact form of the same hierarchy for walks that run once per LANE (rays with their own origins). Such a walk is a chain
+// of dependent fetches, so a node holds FOUR children -- every second level of the binary hierarchy is skipped: the children of
+// a node's internal children take their place -- in 64 bytes: per child three words (lo | hi << 16 per axis, 16-bit steps of a
+// frame around the whole hierarchy: base + q * step, rounded outwards by a step and more) and its reference (a leaf as in the
+// binary form, the index of a wide node, or PT_BVH_NO_CHILD). A triangle record is 48 bytes: a.xyz e1.x | e1.yz e2.xy | e2.z id - -.
+#define PT_BVH_WNODE_WORDS 16
+#ifndef PT_BVH_WIDE_LEAF_MAX
+#define PT_BVH_WIDE_LEAF_MAX 2  // triangles per leaf of the wide form (1M triangles: 11.1 ms at 2, 11.3 at 1, 11.8 at 4)
+#endif
+#define PT_BVH_NO_CHILD 0xffffffffu
+#define PT_BVH_QTRI_FLOATS 12
 #ifndef PT_BVH_LEAF_MAX
 #define PT_BVH_LEAF_MAX 4
 #endif
@@ -66,6 +77,12 @@ struct PtBvhBuild {
     float* nodes;                 // (n-1) x PT_BVH_NODE_FLOATS traversal records
     float* nodes_abs;             // (n-1) x PT_BVH_NODE_FLOATS, absolute boxes
     float* sorted_tris_abs;       // (n + PT_TRI_PAD) x PT_TRI_FLOATS: a, e1, e2 in leaf order
+    int* parent;                  // (n-1): binary parent of each internal node (-1 for the root)
+    int* wide_index;              // (n-1): index of the wide node made of this binary node, or -1 (odd level, or inside a leaf)
+    int* wide_flag;               // (n-1): scratch of the numbering
+    uint32_t* nodes_w;            // up to (n-1) x PT_BVH_WNODE_WORDS: wide nodes, absolute boxes in 16-bit steps of the frame
+    float* tris_q;                // (n + PT_TRI_PAD) x PT_BVH_QTRI_FLOATS: a, e1, e2, id in leaf order
+    float* qframe;                // 8: base xyz, step xyz of the frame, -, -
     float* sorted_tris;           // (n + PT_TRI_PAD) x PT_TRI_FLOATS
     int* sorted_ids;              // n + PT_TRI_PAD
 };
@@ -164,6 +181,9 @@ struct PtKernelParams {
                                         // (pt_render_decoupled_kernel), 2 = all lanes of a wave in step (pt_render_kernel<5, true>)
     int32_t lane_stack_limit;           // entries of a lane's stack that may be used (<= PT_LANE_STACK)
     const float* bvh_tris_abs;          // a, e1, e2 records in leaf order
+    const uint32_t* bvh_nodes_w;        // wide nodes, compact records and frame of the per-lane walks (PT_BVH_WNODE_WORDS, PT_BVH_QTRI_FLOATS)
+    const float* bvh_tris_q;
+    const float* bvh_qframe;
     const float* spheres;               // 10 x 8 floats: per-sphere records for the current camera position (pt_prepare_spheres_kernel)
     const float* src;                   // RGBA32F image read (previous result)
     float* dst;                         // RGBA32F image written

@@ -1049,73 +1049,93 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
 // node steps per round before the lane looks at its leaf (measured on three scenes: 2: +5 %, 3: 0, 5: -6 %, 8: -5 %, 16: +3 %,
 // unbounded: +12 % of the time at 3)
 #ifndef PT_WALK_NODE_STEPS
-#define PT_WALK_NODE_STEPS 5
+#define PT_WALK_NODE_STEPS 3
 #endif
 
 struct LaneWalk {
     uint32_t ref;  // node or leaf reference the lane looks at next
     int sp;        // entries on the lane's stack
     Hit h;
-    float ix, iy, iz, ox, oy, oz;  // reciprocal direction and origin x reciprocal, for the slab tests
+    float ax, ay, az, bx, by, bz;  // a bound stored as q steps of the frame lies at ray parameter fma(q, a, b) on its axis
 };
 
-__device__ __forceinline__ void walk_begin(LaneWalk& w, v3 ro, v3 rd) {
+__device__ __forceinline__ void walk_begin(const PtKernelParams& p, LaneWalk& w, v3 ro, v3 rd) {
     const float tiny = 1.0e-20f;
-    w.ix = __builtin_amdgcn_rcpf(__builtin_fabsf(rd.x) > tiny ? rd.x : __builtin_copysignf(tiny, rd.x));
-    w.iy = __builtin_amdgcn_rcpf(__builtin_fabsf(rd.y) > tiny ? rd.y : __builtin_copysignf(tiny, rd.y));
-    w.iz = __builtin_amdgcn_rcpf(__builtin_fabsf(rd.z) > tiny ? rd.z : __builtin_copysignf(tiny, rd.z));
-    w.ox = ro.x * w.ix; w.oy = ro.y * w.iy; w.oz = ro.z * w.iz;
+    const float ix = __builtin_amdgcn_rcpf(__builtin_fabsf(rd.x) > tiny ? rd.x : __builtin_copysignf(tiny, rd.x));
+    const float iy = __builtin_amdgcn_rcpf(__builtin_fabsf(rd.y) > tiny ? rd.y : __builtin_copysignf(tiny, rd.y));
+    const float iz = __builtin_amdgcn_rcpf(__builtin_fabsf(rd.z) > tiny ? rd.z : __builtin_copysignf(tiny, rd.z));
+    const float* __restrict__ f = p.bvh_qframe;  // base xyz, step xyz
+    w.ax = f[3] * ix; w.ay = f[4] * iy; w.az = f[5] * iz;
+    w.bx = (f[0] - ro.x) * ix; w.by = (f[1] - ro.y) * iy; w.bz = (f[2] - ro.z) * iz;
     w.ref = 0;  // root = internal node 0
     w.sp = 0;
     w.h.t = 1.0e38f; w.h.id = -1; w.h.u = 0.f; w.h.v = 0.f; w.h.ood = 0.f;
 }
 
-// One round of a lane's walk. Returns 0 = more to do, 1 = the walk is over (w.h is the closest hit), 2 = the lane's stack
-// is full (the caller repeats the query with the per-wave walk, which has room for any hierarchy).
-__device__ __forceinline__ int walk_round(const PtKernelParams& p, LaneWalk& w, v3 ro, v3 rd, uint32_t* __restrict__ my, unsigned& steps) {
-    const float4* __restrict__ nodes = reinterpret_cast<const float4*>(p.bvh_nodes_abs);
-    const float4* __restrict__ recs = reinterpret_cast<const float4*>(p.bvh_tris_abs);
-    const float ax = __builtin_fabsf(w.ix), ay = __builtin_fabsf(w.iy), az = __builtin_fabsf(w.iz);
-    for (int s = 0; s < PT_WALK_NODE_STEPS && !(w.ref & 0x80000000u); ++s) {
-        ++steps;
-        const size_t at = 4 * (size_t)w.ref;
-        const float4 n0 = nodes[at], n1 = nodes[at + 1], n2 = nodes[at + 2], n3 = nodes[at + 3];
-        const float limit = w.h.t * 1.0001f;
-        float m, t;
-        m = n0.w * ax; t = __builtin_fmaf(n0.x, w.ix, -w.ox); float lnear = t - m, lfar = t + m;
-        m = n1.x * ay; t = __builtin_fmaf(n0.y, w.iy, -w.oy); const float lny = t - m, lfy = t + m;
-        m = n1.y * az; t = __builtin_fmaf(n0.z, w.iz, -w.oz); const float lnz = t - m, lfz = t + m;
-        lnear = __builtin_fmaxf(__builtin_fmaxf(lnear, lny), __builtin_fmaxf(lnz, 0.0f));
-        lfar = __builtin_fminf(__builtin_fminf(lfar, lfy), __builtin_fminf(lfz, limit));
-        m = n2.y * ax; t = __builtin_fmaf(n1.z, w.ix, -w.ox); float rnear = t - m, rfar = t + m;
-        m = n2.z * ay; t = __builtin_fmaf(n1.w, w.iy, -w.oy); const float rny = t - m, rfy = t + m;
-        m = n2.w * az; t = __builtin_fmaf(n2.x, w.iz, -w.oz); const float rnz = t - m, rfz = t + m;
-        rnear = __builtin_fmaxf(__builtin_fmaxf(rnear, rny), __builtin_fmaxf(rnz, 0.0f));
-        rfar = __builtin_fminf(__builtin_fminf(rfar, rfy), __builtin_fminf(rfz, limit));
-        const bool hl = lnear <= lfar, hr = rnear <= rfar;
-        const uint32_t lref = __float_as_uint(n3.x), rref = __float_as_uint(n3.y);
-        if (hl && hr) {
-            const bool left_first = lnear <= rnear;
-            if (w.sp >= p.lane_stack_limit) return 2;
-            my[w.sp * 64] = left_first ? rref : lref;
-            ++w.sp;
-            w.ref = left_first ? lref : rref;
-        } else if (hl || hr) {
-            w.ref = hl ? lref : rref;
-        } else {
-            if (w.sp == 0) return 1;
-            --w.sp;
-            w.ref = my[w.sp * 64];
+// entry and exit parameter of the ray in one child's box (three words lo | hi << 16), clipped to [0, limit]
+__device__ __forceinline__ void qbox_span(const LaneWalk& w, uint32_t qx, uint32_t qy, uint32_t qz, float limit, float& tnear, float& tfar) {
+    const float x0 = __builtin_fmaf((float)(qx & 0xffffu), w.ax, w.bx), x1 = __builtin_fmaf((float)(qx >> 16), w.ax, w.bx);
+    const float y0 = __builtin_fmaf((float)(qy & 0xffffu), w.ay, w.by), y1 = __builtin_fmaf((float)(qy >> 16), w.ay, w.by);
+    const float z0 = __builtin_fmaf((float)(qz & 0xffffu), w.az, w.bz), z1 = __builtin_fmaf((float)(qz >> 16), w.az, w.bz);
+    tnear = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fmaxf(__builtin_fminf(z0, z1), 0.0f));
+    tfar = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fminf(__builtin_fmaxf(z0, z1), limit));
+}
+
+// One round of the lanes' walks. Called by ALL lanes of the wave, `active` = this lane is walking: the loops below are the
+// wave's, so the counts of records fetched (steps: nodes and triangles, records: triangles; summed over the lanes) stay in
+// scalar registers -- the lanes have no registers to spare for statistics. Returns, per lane, 0 = more to do (or not active),
+// 1 = the walk is over (w.h is the closest hit), 2 = the lane's stack is full (the caller repeats the query with the per-wave
+// walk, which has room for any hierarchy).
+__device__ __forceinline__ int walk_round(const PtKernelParams& p, LaneWalk& w, v3 ro, v3 rd, uint32_t* __restrict__ my, bool active,
+                                          unsigned& steps, unsigned& records) {
+    const uint4* __restrict__ nodes = reinterpret_cast<const uint4*>(p.bvh_nodes_w);
+    const float4* __restrict__ recs = reinterpret_cast<const float4*>(p.bvh_tris_q);
+    int result = 0;
+    for (int s = 0; s < PT_WALK_NODE_STEPS; ++s) {
+        const bool go = active && result == 0 && !(w.ref & 0x80000000u);
+        const unsigned long long going = __builtin_amdgcn_ballot_w64(go);
+        if (!going) break;
+        steps += (unsigned)__builtin_popcountll(going);
+        if (go) {
+            const size_t at = 4 * (size_t)w.ref;
+            const uint4 c0 = nodes[at], c1 = nodes[at + 1], c2 = nodes[at + 2], c3 = nodes[at + 3];
+            const float limit = w.h.t * 1.0001f;
+            const float inf = __builtin_inff();
+            float n0, n1, n2, n3, f;
+            qbox_span(w, c0.x, c0.y, c0.z, limit, n0, f); if (!(n0 <= f) || c0.w == PT_BVH_NO_CHILD) n0 = inf;
+            qbox_span(w, c1.x, c1.y, c1.z, limit, n1, f); if (!(n1 <= f) || c1.w == PT_BVH_NO_CHILD) n1 = inf;
+            qbox_span(w, c2.x, c2.y, c2.z, limit, n2, f); if (!(n2 <= f) || c2.w == PT_BVH_NO_CHILD) n2 = inf;
+            qbox_span(w, c3.x, c3.y, c3.z, limit, n3, f); if (!(n3 <= f) || c3.w == PT_BVH_NO_CHILD) n3 = inf;
+            uint32_t r0 = c0.w, r1 = c1.w, r2 = c2.w, r3 = c3.w;
+            // children in the order the ray enters them (those it misses last): a sorting network on four keys
+#define PT_ORDER(na, ra, nb, rb) { const bool sw = nb < na; const float tn = sw ? na : nb; na = sw ? nb : na; nb = tn; \
+                                   const uint32_t tr = sw ? ra : rb; ra = sw ? rb : ra; rb = tr; }
+            PT_ORDER(n0, r0, n1, r1) PT_ORDER(n2, r2, n3, r3) PT_ORDER(n0, r0, n2, r2) PT_ORDER(n1, r1, n3, r3) PT_ORDER(n1, r1, n2, r2)
+#undef PT_ORDER
+            const int hits = (n0 < inf) + (n1 < inf) + (n2 < inf) + (n3 < inf);
+            if (hits == 0) {
+                if (w.sp == 0) {
+                    result = 1;
+                } else {
+                    --w.sp;
+                    w.ref = my[w.sp * 64];
+                }
+            } else if (w.sp + hits - 1 > p.lane_stack_limit) {
+                result = 2;
+            } else {
+                // the nearest next, the others wait on the stack, the farthest deepest
+                if (hits > 3) { my[w.sp * 64] = r3; ++w.sp; }
+                if (hits > 2) { my[w.sp * 64] = r2; ++w.sp; }
+                if (hits > 1) { my[w.sp * 64] = r1; ++w.sp; }
+                w.ref = r0;
+            }
         }
     }
-    if (!(w.ref & 0x80000000u)) return 0;
-    // leaf: up to PT_BVH_LEAF_MAX consecutive records, requested together
-    const int first = (int)((w.ref & 0x7fffffffu) >> 3), count = (int)(w.ref & 7u) + 1;
-    for (int k = 0; k < count; ++k) {
-        ++steps;
-        const size_t at = 4 * (size_t)(first + k);
-        const float4 ra = recs[at], rb = recs[at + 1], rc = recs[at + 2], rdd = recs[at + 3];
-        // fs:136-168 as written: record = a.xyz e1.x | e1.yz e2.xy | e2.z - - - | - - - id
+    // leaf: up to PT_BVH_WIDE_LEAF_MAX consecutive records
+    const bool leaf = active && result == 0 && (w.ref & 0x80000000u);
+    const int first = (int)((w.ref & 0x7fffffffu) >> 3), count = leaf ? (int)(w.ref & 7u) + 1 : 0;
+    auto test_record = [&](const float4 ra, const float4 rb, const float4 rc, bool live) {
+        // fs:136-168 as written: record = a.xyz e1.x | e1.yz e2.xy | e2.z id - -
         const v3 a = V(ra.x, ra.y, ra.z), e1 = V(ra.w, rb.x, rb.y), e2 = V(rb.z, rb.w, rc.x);
         const v3 q = cross3(rd, e2);
         const float det = dot3(e1, q);
@@ -1123,19 +1143,55 @@ __device__ __forceinline__ int walk_round(const PtKernelParams& p, LaneWalk& w, 
         const v3 r = cross3(ap, e1);
         const float u = dot3(ap, q);
         const float v = dot3(rd, r);
-        if ((det >= 0.0001f) & (u >= 0.0f) & (v >= 0.0f) & ((u + v) <= det)) {
+        if (live & (det >= 0.0001f) & (u >= 0.0f) & (v >= 0.0f) & ((u + v) <= det)) {
             const float ood = ieee_rcp(det);
             const float tt = dot3(e2, r) * ood;
-            const int id = (int)__float_as_uint(rdd.w);
+            const int id = (int)__float_as_uint(rc.y);
             if (tt > 0.0f && (tt < w.h.t || (tt == w.h.t && id < w.h.id))) {
                 w.h.t = tt; w.h.id = id; w.h.u = u; w.h.v = v; w.h.ood = ood;
             }
         }
+    };
+#if PT_BVH_WIDE_LEAF_MAX == 2
+    {   // both records are requested before either is looked at (one wait instead of two)
+        const unsigned long long at_leaf = __builtin_amdgcn_ballot_w64(leaf);
+        if (at_leaf) {
+            const bool two = count > 1;
+            const unsigned n = (unsigned)__builtin_popcountll(at_leaf) + (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(two));
+            steps += n;
+            records += n;
+            if (leaf) {
+                const size_t at0 = 3 * (size_t)first, at1 = 3 * (size_t)(first + (two ? 1 : 0));
+                const float4 a0 = recs[at0], b0 = recs[at0 + 1], c0 = recs[at0 + 2];
+                const float4 a1 = recs[at1], b1 = recs[at1 + 1], c1 = recs[at1 + 2];
+                test_record(a0, b0, c0, true);
+                test_record(a1, b1, c1, two);
+            }
+        }
     }
-    if (w.sp == 0) return 1;
-    --w.sp;
-    w.ref = my[w.sp * 64];
-    return 0;
+#else
+    for (int k = 0; k < 8; ++k) {
+        const bool go = k < count;
+        const unsigned long long going = __builtin_amdgcn_ballot_w64(go);
+        if (!going) break;
+        const unsigned n = (unsigned)__builtin_popcountll(going);
+        steps += n;
+        records += n;
+        if (go) {
+            const size_t at = 3 * (size_t)(first + k);
+            test_record(recs[at], recs[at + 1], recs[at + 2], true);
+        }
+    }
+#endif
+    if (leaf) {
+        if (w.sp == 0) {
+            result = 1;
+        } else {
+            --w.sp;
+            w.ref = my[w.sp * 64];
+        }
+    }
+    return result;
 }
 
 // waves per SIMD the register allocation must allow: the walk waits on dependent fetches most of the time, so a fifth wave
@@ -1171,6 +1227,14 @@ __global__ __launch_bounds__(64, PT_DECOUPLED_MIN_WAVES) void pt_render_decouple
     int remaining = in_window ? sample_count : 0;
     int sample = p.first_sample + sample_begin * p.sample_stride;
     unsigned rays = 0, traced = 0, batches = 0, rounds = 0, shaded = 0, steps = 0, node_visits = 0, tri_tests = 0;
+    unsigned wsteps = 0, wrecords = 0;  // of the walk rounds: per wave
+#ifdef PT_V_STATE_COUNT
+    unsigned st_rounds = 0, st_walk = 0, st_wait = 0, st_shade_lanes = 0;  // measurement build: lane states per loop trip
+    unsigned long long tk_hand = 0, tk_shade = 0, tk_walk = 0, tk_mark = __builtin_amdgcn_s_memtime();
+#define PT_PHASE_D(acc) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - tk_mark; tk_mark = now_; }
+#else
+#define PT_PHASE_D(acc)
+#endif
 
     // the camera ray of the pixel, once (the shader has no pixel jitter): every sample starts from its hit
     const bool reuse = p.primary_reuse != 0 && p.depth > 0;
@@ -1228,19 +1292,26 @@ __global__ __launch_bounds__(64, PT_DECOUPLED_MIN_WAVES) void pt_render_decouple
     float pend_t = t0;
     int pend_id = id0;
     LaneWalk w;
-    walk_begin(w, ro0, rd0);
+    walk_begin(p, w, ro0, rd0);
     int state = remaining > 0 ? SHADE : DONE;
     if (state == SHADE && !reuse && p.depth > 0) {  // no reuse: the sample's first query is the camera ray itself
         state = WALK;
         ++traced; ++rays;
     }
 
+    PT_PHASE_D(tk_hand)
     for (;;) {
         const unsigned long long walking = __builtin_amdgcn_ballot_w64(state == WALK);
         const unsigned long long waiting = __builtin_amdgcn_ballot_w64(state == SHADE);
         if (!walking && !waiting) break;
+#ifdef PT_V_STATE_COUNT
+        st_rounds += 1; st_walk += __builtin_popcountll(walking); st_wait += __builtin_popcountll(waiting);
+#endif
         if (waiting && (__builtin_popcountll(waiting) >= PT_SHADE_BATCH || !walking)) {
             ++batches;
+#ifdef PT_V_STATE_COUNT
+            st_shade_lanes += __builtin_popcountll(waiting);
+#endif
             // Shade() of the pending hit, the end of the sample, the start of the next query: until the lane walks again or
             // has no samples left (a sample that ends starts the next one from the reused camera-ray hit at once)
             while (state == SHADE) {
@@ -1256,7 +1327,7 @@ __global__ __launch_bounds__(64, PT_DECOUPLED_MIN_WAVES) void pt_render_decouple
                     done = !pend_hit || spent || level >= p.depth;
                 }
                 if (!done) {
-                    walk_begin(w, ro, rd);
+                    walk_begin(p, w, ro, rd);
                     state = WALK;
                     ++traced; ++rays;
                     break;
@@ -1277,15 +1348,16 @@ __global__ __launch_bounds__(64, PT_DECOUPLED_MIN_WAVES) void pt_render_decouple
                     pend_hit = hit0; pend_n = N0; pend_t = t0; pend_id = id0;
                     ++rays;  // the new sample's camera-ray query, answered by the reused result
                 } else if (p.depth > 0) {
-                    walk_begin(w, ro0, rd0);
+                    walk_begin(p, w, ro0, rd0);
                     state = WALK;
                     ++traced; ++rays;
                     break;
                 }
             }
         }
+        PT_PHASE_D(tk_shade)
+        const int r = walk_round(p, w, ro, rd, my, state == WALK, wsteps, wrecords);
         if (state == WALK) {
-            const int r = walk_round(p, w, ro, rd, my, steps);
             if (r == 2) state = FULL;
             else if (r == 1) {
                 pend_hit = w.h.id >= 0;
@@ -1305,12 +1377,13 @@ __global__ __launch_bounds__(64, PT_DECOUPLED_MIN_WAVES) void pt_render_decouple
             }
         }
         ++rounds;
+        PT_PHASE_D(tk_walk)
     }
     if (in_window && scratch_slot < 0) {
         const float alpha = p.accum_mode == 0 ? 1.0f : prev.w + (float)p.num_samples;
         reinterpret_cast<float4*>(p.dst)[pix] = make_float4(mr, mg, mb, alpha);
     }
-    const unsigned long long wave_rays = wave_sum(rays), wave_traced = wave_sum(traced), wave_steps = wave_sum(steps), wave_shaded = wave_sum(shaded);
+    const unsigned long long wave_rays = wave_sum(rays), wave_traced = wave_sum(traced), wave_steps = wave_sum(steps) + wsteps, wave_shaded = wave_sum(shaded), wave_records = wrecords;
     if ((threadIdx.x & 63) == 0 && wave_rays) {
         unsigned long long* counters = p.counters + (size_t)(blockIdx.x % PT_COUNTER_SLOTS) * PT_COUNTER_STRIDE;
         atomicAdd(&counters[0], wave_rays);
@@ -1320,7 +1393,17 @@ __global__ __launch_bounds__(64, PT_DECOUPLED_MIN_WAVES) void pt_render_decouple
         atomicAdd(&counters[2], (unsigned long long)__builtin_amdgcn_readfirstlane(node_visits));
         atomicAdd(&counters[3], (unsigned long long)__builtin_amdgcn_readfirstlane(tri_tests));
         atomicAdd(&counters[5], wave_steps);
+        atomicAdd(&counters[9], wave_records);
         if (wave_shaded) atomicAdd(&counters[6], wave_shaded);
+#ifdef PT_V_STATE_COUNT
+        atomicAdd(&counters[2], (unsigned long long)st_rounds);       // reported as bvh_node_fetches
+        atomicAdd(&counters[3], (unsigned long long)st_walk);         // bvh_triangle_fetches
+        atomicAdd(&counters[7], (unsigned long long)st_wait);         // loop_triangle_visits
+        atomicAdd(&counters[8], (unsigned long long)st_shade_lanes);  // loop_full_tests
+        atomicAdd(&counters[10], tk_hand);
+        atomicAdd(&counters[11], tk_shade);
+        atomicAdd(&counters[12], tk_walk);
+#endif
     }
 }
 
@@ -1506,8 +1589,8 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_primary_kernel(const PtKer
 // whose distance differs in any bit. The path continues along the loop's answer.
 template <int KIND, bool MATERIALS>
 __global__ __launch_bounds__(PT_TILE_THREADS) void pt_verify_kernel(const PtKernelParams p) {
-    __shared__ uint32_t s_stack[(KIND == 2 || KIND == 5) ? PT_TILE_WAVES : 1][(KIND == 2 || KIND == 5) ? PT_BVH_STACK : 1];
-    __shared__ uint32_t s_lane_stack[KIND == 5 ? PT_TILE_WAVES : 1][KIND == 5 ? PT_LANE_STACK * 64 : 1];
+    __shared__ uint32_t s_stack[(KIND == 2 || KIND == 5 || KIND == 6) ? PT_TILE_WAVES : 1][(KIND == 2 || KIND == 5 || KIND == 6) ? PT_BVH_STACK : 1];
+    __shared__ uint32_t s_lane_stack[(KIND == 5 || KIND == 6) ? PT_TILE_WAVES : 1][(KIND == 5 || KIND == 6) ? PT_LANE_STACK * 64 : 1];
     int x, y;
     bool live = pixel_of_lane(p, (int)blockIdx.x, x, y);
     Rng rng;
@@ -1530,6 +1613,14 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_verify_kernel(const PtKern
                 bool overflow;
                 b = intersect_bvh_lanes(p, ro, rd, s_lane_stack[threadIdx.x >> 6], overflow, tt);
                 if (overflow) b = intersect_bvh<true>(p, ro, rd, s_stack[threadIdx.x >> 6], nv, tt);
+            } else if (KIND == 6) {  // the wide hierarchy, walked in rounds as pt_render_decoupled_kernel walks it
+                LaneWalk w;
+                walk_begin(p, w, ro, rd);
+                uint32_t* my = s_lane_stack[threadIdx.x >> 6] + (threadIdx.x & 63);
+                int r;
+                do { r = walk_round(p, w, ro, rd, my, true, nv, tt); } while (r == 0);
+                b = w.h;
+                if (r == 2) b = intersect_bvh<true>(p, ro, rd, s_stack[threadIdx.x >> 6], nv, tt);
             } else b = intersect_grid(p, rd, tt, gn);
             ++compared;
             bad_id += a.id != b.id ? 1u : 0u;
@@ -1988,7 +2079,8 @@ hipError_t pt_launch_verify(const PtKernelParams& p, hipStream_t stream) {
     if (p.win_w <= 0 || p.win_h <= 0) return hipSuccess;
     const dim3 grid(window_tiles(p)), block(PT_TILE_THREADS);
     if (p.shading_mode != 0) {
-        if (p.bvh_nodes_abs && p.lane_walk) hipLaunchKernelGGL((pt_verify_kernel<5, true>), grid, block, 0, stream, p);
+        if (p.bvh_nodes_abs && p.lane_walk == 1 && PT_TILE_WAVES == 1) hipLaunchKernelGGL((pt_verify_kernel<6, true>), grid, block, 0, stream, p);
+        else if (p.bvh_nodes_abs && p.lane_walk) hipLaunchKernelGGL((pt_verify_kernel<5, true>), grid, block, 0, stream, p);
         else if (p.bvh_nodes_abs) hipLaunchKernelGGL((pt_verify_kernel<2, true>), grid, block, 0, stream, p);
         else return hipErrorInvalidValue;  // the materials mode without a hierarchy IS the all-triangles loop
     }

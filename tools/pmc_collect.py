@@ -36,6 +36,9 @@ PASSES = {
             "SQ_ACTIVE_INST_ANY", "SQ_INSTS_SMEM"],
     "fetch": ["FETCH_SIZE", "TCC_HIT_sum"],
     "write": ["WRITE_SIZE", "TCC_MISS_sum"],
+    # the vector memory path of a compute unit: address unit (TA), L1 (TCP), data return (TD)
+    "mem": ["TA_TA_BUSY_sum", "TA_ADDR_STALLED_BY_TC_CYCLES_sum", "TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "TCP_PENDING_STALL_CYCLES_sum",
+            "TCP_TCP_TA_DATA_STALL_CYCLES_sum", "TD_TD_BUSY_sum", "TD_TC_STALL_sum", "SQ_INSTS_VMEM_RD", "SQ_ACTIVE_INST_VMEM", "SQ_WAVE_CYCLES"],
 }
 
 
@@ -135,6 +138,13 @@ def collect(tag, bench_args):
         "write_bytes_per_launch": c["WRITE_SIZE"] * 1024.0,
         "hbm_bytes_per_launch": 2.0 * c["FETCH_SIZE"] * 1024.0 + c["WRITE_SIZE"] * 1024.0,
         "l2_hit_rate": c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]) if c.get("TCC_HIT_sum") is not None and (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]) else None,
+        # shares of the kernel's cycles, averaged over the 256 compute units; L1 accesses = 64-byte line look-ups
+        "ta_busy_share": c["TA_TA_BUSY_sum"] / (256.0 * cycles) if "TA_TA_BUSY_sum" in c else None,
+        "td_busy_share": c["TD_TD_BUSY_sum"] / (256.0 * cycles) if "TD_TD_BUSY_sum" in c else None,
+        "l1_accesses_per_cycle_per_cu": c["TCP_TOTAL_CACHE_ACCESSES_sum"] / (256.0 * cycles) if "TCP_TOTAL_CACHE_ACCESSES_sum" in c else None,
+        "l1_miss_share": c["TCP_TCC_READ_REQ_sum"] / c["TCP_TOTAL_CACHE_ACCESSES_sum"] if c.get("TCP_TOTAL_CACHE_ACCESSES_sum") else None,
+        "l1_pending_stall_share": c["TCP_PENDING_STALL_CYCLES_sum"] / (256.0 * cycles) if "TCP_PENDING_STALL_CYCLES_sum" in c else None,
+        "l1_accesses_per_vmem_read_inst": c["TCP_TOTAL_CACHE_ACCESSES_sum"] / c["SQ_INSTS_VMEM_RD"] if c.get("SQ_INSTS_VMEM_RD") and "TCP_TOTAL_CACHE_ACCESSES_sum" in c else None,
         "bench_roofline_of_the_trace_run": {k: bench_line["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel_ms")},
     }
     cfgw = bench_line["config"]["workload"].split()
@@ -142,7 +152,8 @@ def collect(tag, bench_args):
     entry["key"] = bench.config_key(a.workload, int(w), int(h), a.spp, a.shading, a.accel)
     json.dump(entry, open(os.path.join(OUT, f"{tag}.json"), "w"), indent=1)
     print(json.dumps({k: entry[k] for k in ("key", "kernel", "kernel_ms", "kernel_ms_rocprof_stats_avg", "valu_issue_share", "wait_inst_share",
-                                            "fp32_share_of_valu_insts", "active_lane_share_of_valu", "hbm_bytes_per_launch", "l2_hit_rate")}, indent=1))
+                                            "fp32_share_of_valu_insts", "active_lane_share_of_valu", "hbm_bytes_per_launch", "l2_hit_rate", "ta_busy_share", "td_busy_share",
+                                            "l1_accesses_per_cycle_per_cu", "l1_miss_share", "l1_pending_stall_share", "l1_accesses_per_vmem_read_inst")}, indent=1))
 
 
 def merge():
