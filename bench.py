@@ -108,6 +108,21 @@ def pmc_entry(key):
     return e, None
 
 
+def gather_probe_rates():
+    """Record rates (G records/s, chip-wide) of tools/gather_probe.hip on MI355X -- every lane chasing its own chain of 64-byte
+    records with 16-byte loads at 20 waves per CU, 64 lanes active: from a footprint that stays in the L2s, and from one that
+    does not -- out of the tracked result file, or None."""
+    try:
+        rows = json.load(open(os.path.join(ROOT, "profiles", "r02_gather_probe.json")))["rows"]
+    except (OSError, ValueError, KeyError):
+        return None
+    pick = {r["footprint_MiB"]: r["Grecords_per_s"] for r in rows
+            if r["bytes_per_record"] == 64 and r["waves_per_cu"] == 20 and r["active_lanes"] == 64}
+    if 2 not in pick or 128 not in pick:
+        return None
+    return {"l2_resident": pick[2], "beyond_l2": pick[128]}
+
+
 def which_kernel(st, program, shading):
     if program == 0:
         return "pt_render_kernel<0,false>", "spheres"
@@ -157,6 +172,19 @@ def roofline(st, kernel_ms, scene, shading, pmc, pmc_note):
                             + ("per lane" if kind == "lane_walk" else "once per wave, scalar fetches") +
                             "), priced against the random-row gather rate of the level their footprint fits "
                             "(MI355X_MICROARCH.md: L2 16.8, Infinity Cache 8.6, HBM 8.0 TB/s)"})
+        probe = gather_probe_rates() if kind == "lane_walk" else None
+        if probe and sec > 0:
+            # the same access shape measured bare (tools/gather_probe.hip): what the memory side allows a walk that does nothing
+            # but fetch. With the L2 hit rate of the profiled run the two rates blend into the ceiling for THIS mix of hits.
+            rate = recs / sec * 1e-9
+            dep = {"achieved_Grecords_per_s": rate, "l2_resident_Grecords_per_s": probe["l2_resident"],
+                   "beyond_l2_Grecords_per_s": probe["beyond_l2"], "frac_of_l2_resident": rate / probe["l2_resident"],
+                   "source": "profiles/r02_gather_probe.json (tools/gather_probe.hip: 64-byte records, 20 waves per CU, 64 lanes)"}
+            h = pmc.get("l2_hit_rate") if pmc else None
+            if h is not None:
+                ceiling = 1.0 / (h / probe["l2_resident"] + (1.0 - h) / probe["beyond_l2"])
+                dep.update({"l2_hit_rate": h, "ceiling_at_that_hit_rate_Grecords_per_s": ceiling, "frac_of_ceiling": rate / ceiling})
+            out["dependent_gather"] = dep
     else:
         shade = FLOP["shade_materials"] if shading == "materials" else FLOP["shade_reference"]
         if scene.program != 0 and scene.normal_mode == 0:
