@@ -200,9 +200,17 @@ def roofline(st, kernel_ms, scene, shading, pmc, pmc_note):
             per_lane_tests = per["loop_triangle_visits"] * 64.0 * lane_util
             first, rest = (FLOP["test_from_first"], FLOP["test_from_rest"]) if kind == "loop_from" else (FLOP["loop_first"], FLOP["loop_rest"])
             past_skip = per["loop_full_tests"] / per["loop_triangle_visits"] if per["loop_triangle_visits"] else 0.0
+            out["loop_tests_past_backface_skip"] = past_skip
+            if not per["loop_full_tests"]:
+                # the product build does not count them (one VALU instruction per record): the tracked profile of this
+                # configuration carries the share measured with the counting build, else only the part before the skip is priced
+                if pmc and pmc.get("loop_tests_past_backface_skip") is not None:
+                    past_skip = pmc["loop_tests_past_backface_skip"]
+                    out["loop_tests_past_backface_skip"] = past_skip
+                    out["loop_tests_past_backface_skip_source"] = "profiles/r02_pmc.json (counting build, same configuration)"
+                else:
+                    out["loop_tests_past_backface_skip"] = "not counted in the product build: only the part of a test before the skip is priced"
             flop += per_lane_tests * (first + rest * past_skip) + per["shaded_hits"] * FLOP["test_accept"]
-            out["loop_tests_past_backface_skip"] = past_skip if per["loop_full_tests"] else \
-                "not counted in the product build: only the part of a test before the skip is priced"
         tf = flop / sec * 1e-12 if sec > 0 else 0.0
         out.update({"bound": "valu", "achieved": tf, "peak": PEAK_FP32_UNFUSED_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_UNFUSED_TFLOPS,
                     "peak_fma_nominal": PEAK_FP32_FMA_TFLOPS, "frac_of_fma_nominal": tf / PEAK_FP32_FMA_TFLOPS,
@@ -221,6 +229,10 @@ def roofline(st, kernel_ms, scene, shading, pmc, pmc_note):
                                           "active_lane_share_of_valu", "fp32_share_of_valu_insts", "hw_fp32_flop_per_launch_active_lanes",
                                           "wait_inst_share", "wait_any_share", "l2_hit_rate", "fetch_bytes_per_launch", "write_bytes_per_launch",
                                           "kernel_ms", "kernel_ms_rocprof_stats_avg") if k in pmc}
+        if pmc.get("hw_fp32_flop_per_launch_active_lanes") and pmc.get("kernel_ms") and out.get("unit") == "TFLOP/s":
+            # the same quantity from the hardware's instruction counters of the profiled run (add + mul + 2 fma + transcendental
+            # instructions x 64 x the share of lanes switched on)
+            out["frac_from_counters"] = pmc["hw_fp32_flop_per_launch_active_lanes"] / (pmc["kernel_ms"] * 1e-3) * 1e-12 / PEAK_FP32_UNFUSED_TFLOPS
         if out["traffic"] and sec > 0:
             out["hbm_GB_per_s"] = out["traffic"] / (pmc.get("kernel_ms", kernel_ms) * 1e-3) * 1e-9
             out["hbm_frac"] = out["hbm_GB_per_s"] / 8000.0

@@ -58,7 +58,8 @@ def main():
                       "rays_per_sample": st["rays"] / st["samples"], "lane_utilisation": st["rays_traced"] / max(1, st["lane_slots"]),
                       "triangle_records_per_wave_ray": st["bvh_triangle_fetches"] * 64 / st["lane_slots"],
                       "grid_tests_per_traced_ray": st["grid_triangle_tests"] / max(1, st["rays_traced"]), "grid_entries": st["grid_entries"],
-                      "node_records_per_wave_ray": st["bvh_node_fetches"] * 64 / st["lane_slots"]}))
+                      "node_records_per_wave_ray": st["bvh_node_fetches"] * 64 / st["lane_slots"],
+                      "loop_triangle_visits": st["loop_triangle_visits"], "loop_full_tests": st["loop_full_tests"]}))
     t.close()
 
 

@@ -147,6 +147,18 @@ def collect(tag, bench_args):
         "l1_accesses_per_vmem_read_inst": c["TCP_TOTAL_CACHE_ACCESSES_sum"] / c["SQ_INSTS_VMEM_RD"] if c.get("SQ_INSTS_VMEM_RD") and "TCP_TOTAL_CACHE_ACCESSES_sum" in c else None,
         "bench_roofline_of_the_trace_run": {k: bench_line["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel_ms")},
     }
+    # all-triangles loops: the share of record visits that goes past the wave-uniform back-face skip is counted only by the
+    # measurement build of the library (-DPT_V_COUNT_FULL, one more VALU instruction per record), when it has been built
+    variant = os.path.join(ROOT, "pathtracer_amd", "lib", "libpt_hip__countfull.so")
+    if "<1," in short_name(kernel_name) and os.path.exists(variant):
+        cmd = ["python3", os.path.join(ROOT, "tools", "one_dispatch.py"), "--lib", variant, "--workload", a.workload, "--spp", str(a.spp),
+               "--shading", a.shading, "--accel", a.accel, "--reps", "1"]
+        r = subprocess.run(["timeout", "-k", "10", "120"] + cmd, capture_output=True, text=True)
+        if r.returncode == 0:
+            d1 = json.loads(r.stdout.strip().splitlines()[-1])
+            if d1["loop_triangle_visits"]:
+                entry["loop_tests_past_backface_skip"] = d1["loop_full_tests"] / d1["loop_triangle_visits"]
+                entry["loop_tests_past_backface_skip_source"] = "tools/one_dispatch.py with the -DPT_V_COUNT_FULL build, same workload"
     cfgw = bench_line["config"]["workload"].split()
     w, h = cfgw[1].rstrip(",").split("x")
     entry["key"] = bench.config_key(a.workload, int(w), int(h), a.spp, a.shading, a.accel)
