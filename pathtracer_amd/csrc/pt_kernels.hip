@@ -1215,19 +1215,24 @@ __global__ __launch_bounds__(64, PT_DECOUPLED_MIN_WAVES) void pt_render_decouple
     Rng rng;
     rng.fcx = (float)x + 0.5f;
     rng.fcy = (float)y + 0.5f;
-    const v3 rd0 = primary_direction(p, rng.fcx, rng.fcy);
-    float4 prev = make_float4(0.f, 0.f, 0.f, 1.f);
-    if (in_window && scratch_slot < 0) prev = reinterpret_cast<const float4*>(p.src)[pix];
-    float mr = prev.x, mg = prev.y, mb = prev.z;
-    float4* __restrict__ scratch = nullptr;
+    rng.samples = 0.0f;
+    rng.sx = 0.0f;
+    float mr = 0.f, mg = 0.f, mb = 0.f, malpha = 1.0f;
+    if (in_window && scratch_slot < 0) {
+        const float4 prev = reinterpret_cast<const float4*>(p.src)[pix];
+        mr = prev.x; mg = prev.y; mb = prev.z;
+        if (p.accum_mode != 0) malpha = prev.w + (float)p.num_samples;
+    }
+    float4* __restrict__ scratch = nullptr;  // where the pixel's next sample is parked (split tiles)
     if (scratch_slot >= 0)
         scratch = reinterpret_cast<float4*>(p.sample_scratch) + ((size_t)scratch_slot * p.num_samples + sample_begin) * PT_TILE_THREADS + threadIdx.x;
     uint32_t* __restrict__ my = s_lane_stack + (threadIdx.x & 63);
 
     int remaining = in_window ? sample_count : 0;
     int sample = p.first_sample + sample_begin * p.sample_stride;
-    unsigned rays = 0, traced = 0, batches = 0, rounds = 0, shaded = 0, steps = 0, node_visits = 0, tri_tests = 0;
-    unsigned wsteps = 0, wrecords = 0;  // of the walk rounds: per wave
+    // statistics of the wave, counted where all its lanes are together (scalar registers: the lanes have none to spare)
+    unsigned traced = 0, batches = 0, rounds = 0, shaded = 0, steps = 0, records = 0, node_visits = 0, tri_tests = 0;
+    const unsigned pixels = (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(remaining > 0));
 #ifdef PT_V_STATE_COUNT
     unsigned st_rounds = 0, st_walk = 0, st_wait = 0, st_shade_lanes = 0;  // measurement build: lane states per loop trip
     unsigned long long tk_hand = 0, tk_shade = 0, tk_walk = 0, tk_mark = __builtin_amdgcn_s_memtime();
@@ -1236,26 +1241,10 @@ __global__ __launch_bounds__(64, PT_DECOUPLED_MIN_WAVES) void pt_render_decouple
 #define PT_PHASE_D(acc)
 #endif
 
-    // the camera ray of the pixel, once (the shader has no pixel jitter): every sample starts from its hit
-    const bool reuse = p.primary_reuse != 0 && p.depth > 0;
-    v3 N0 = V(0.f, 0.f, 0.f);
-    float t0 = 1.0e38f;
-    int id0 = -1;
-    bool hit0 = false;
-    if (reuse && remaining > 0) {
-        bool overflow;
-        Hit h = intersect_bvh_lanes(p, ro0, rd0, s_lane_stack, overflow, steps);
-        if (overflow) h = intersect_bvh<true>(p, ro0, rd0, s_stack, node_visits, tri_tests);
-        hit0 = h.id >= 0;
-        if (hit0) N0 = mesh_normal(p, h);
-        t0 = h.t; id0 = h.id;
-        ++traced; ++rays;
-    }
-    if (__builtin_amdgcn_ballot_w64(reuse && remaining > 0)) ++batches;
-
-    auto fold = [&](float sr, float sg, float sb, int k) {
+    auto fold = [&](float sr, float sg, float sb) {
         if (scratch_slot >= 0) {
-            scratch[(size_t)k * PT_TILE_THREADS] = make_float4(sr, sg, sb, 0.f);
+            *scratch = make_float4(sr, sg, sb, 0.f);
+            scratch += PT_TILE_THREADS;
         } else if (p.accum_mode == 0) {
             const float a = ieee_rcp((float)sample);
             mr = mr + a * (sr - mr);
@@ -1264,40 +1253,48 @@ __global__ __launch_bounds__(64, PT_DECOUPLED_MIN_WAVES) void pt_render_decouple
         } else {
             mr += sr; mg += sg; mb += sb;
         }
+        --remaining;
+        sample += p.sample_stride;
     };
 
-    // a pixel whose camera ray leaves the scene: every sample is the sky colour of that direction (fs:408-410 with energy 1)
-    if (reuse && !hit0 && remaining > 0) {
-        const float t = 0.5f * (rd0.y + 1.0f);
-        const float omt = 1.0f - t;
-        const float sr = omt + 0.5f * t, sg = omt + 0.7f * t, sb = omt + 1.0f * t;
-        rays += (unsigned)(remaining - 1);
-        for (int k = 0; k < sample_count; ++k) {
-            if (scratch_slot < 0 && p.accum_mode == 0 && mr == sr && mg == sg && mb == sb) break;  // further folds leave it as it is
-            fold(sr, sg, sb, k);
-            sample += p.sample_stride;
-        }
-        remaining = 0;
-    }
-
     enum { WALK = 0, SHADE = 1, DONE = 2, FULL = 3 };
-    // path state of the sample in flight
-    v3 ro = ro0, rd = rd0;
-    v3 energy = V(1.0f, 1.0f, 1.0f), emitted = V(0.f, 0.f, 0.f);
+    // The camera ray of the pixel is evaluated once (the shader has no pixel jitter): with reuse every sample starts from its
+    // hit; its normal is formed by the first Shade() that needs it. It is the lane's first walk, like any other.
+    const bool reuse = p.primary_reuse != 0 && p.depth > 0;
+    bool primary = reuse, hit0 = false, n0_known = false;
+    v3 N0 = V(0.f, 0.f, 0.f);
+    float t0 = 1.0e38f;
+    int id0 = -1;
+    // the sample in flight; the hit it waits to shade is the camera ray's (level 0 with reuse) or the one its walk left in w.h
+    v3 ro = ro0, rd = primary_direction(p, rng.fcx, rng.fcy);
+    v3 energy = V(1.0f, 1.0f, 1.0f);
     int level = 0;
-    rng.samples = (float)sample;
-    rng.sx = 0.0f;
-    bool pend_hit = hit0;
-    v3 pend_n = N0;
-    float pend_t = t0;
-    int pend_id = id0;
     LaneWalk w;
-    walk_begin(p, w, ro0, rd0);
-    int state = remaining > 0 ? SHADE : DONE;
-    if (state == SHADE && !reuse && p.depth > 0) {  // no reuse: the sample's first query is the camera ray itself
-        state = WALK;
-        ++traced; ++rays;
-    }
+    walk_begin(p, w, ro, rd);
+    int state = remaining > 0 ? (p.depth > 0 ? WALK : SHADE) : DONE;
+    traced += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(state == WALK));
+
+    // the walk of the lane's query is over, its result in w.h
+    auto walk_over = [&]() {
+        if (primary) {
+            primary = false;
+            hit0 = w.h.id >= 0; t0 = w.h.t; id0 = w.h.id;
+            if (!hit0) {
+                // the camera ray leaves the scene: every sample is the sky colour of that direction (fs:408-410 with energy 1)
+                const float t = 0.5f * (rd.y + 1.0f);
+                const float omt = 1.0f - t;
+                const float sr = omt + 0.5f * t, sg = omt + 0.7f * t, sb = omt + 1.0f * t;
+                while (remaining > 0) {
+                    if (scratch_slot < 0 && p.accum_mode == 0 && mr == sr && mg == sg && mb == sb) break;  // further folds leave it as it is
+                    fold(sr, sg, sb);
+                }
+                remaining = 0;
+                state = DONE;
+                return;
+            }
+        }
+        state = SHADE;
+    };
 
     PT_PHASE_D(tk_hand)
     for (;;) {
@@ -1313,88 +1310,95 @@ __global__ __launch_bounds__(64, PT_DECOUPLED_MIN_WAVES) void pt_render_decouple
             st_shade_lanes += __builtin_popcountll(waiting);
 #endif
             // Shade() of the pending hit, the end of the sample, the start of the next query: until the lane walks again or
-            // has no samples left (a sample that ends starts the next one from the reused camera-ray hit at once)
-            while (state == SHADE) {
-                bool done = p.depth <= 0;
-                if (!done) {
-                    if (pend_hit) {
-                        ++shaded;
-                        const v3 P = ro + rd * pend_t;  // recPoint, fs:163
-                        shade_materials(rng, p.materials, p.material_ids[pend_id], energy, emitted, ro, rd, P, pend_n, p.shading_mode == 2);
+            // has no samples left (a sample that ends starts the next one from the reused camera-ray hit at once). The loop
+            // is the wave's: a lane takes part while it has something to shade.
+            for (;;) {
+                const bool go = state == SHADE;
+                if (!__builtin_amdgcn_ballot_w64(go)) break;
+                bool shades = false;
+                if (go) {
+                    bool done = p.depth <= 0;
+                    v3 emitted = V(0.f, 0.f, 0.f);  // an emitter ends the path in the Shade() that finds it
+                    if (!done) {
+                        const bool from_camera = reuse && level == 0;
+                        const bool hit = from_camera ? hit0 : w.h.id >= 0;
+                        if (hit) {
+                            shades = true;
+                            v3 n;
+                            if (from_camera) {
+                                if (!n0_known) { N0 = mesh_normal(p, w.h); n0_known = true; }  // w.h still holds the camera ray's walk
+                                n = N0;
+                            } else {
+                                n = mesh_normal(p, w.h);
+                            }
+                            rng.samples = (float)sample;
+                            const v3 P = ro + rd * (from_camera ? t0 : w.h.t);  // recPoint, fs:163
+                            shade_materials(rng, p.materials, p.material_ids[from_camera ? id0 : w.h.id], energy, emitted, ro, rd, P, n, p.shading_mode == 2);
+                        }
+                        ++level;
+                        const bool spent = energy.x == 0.0f && energy.y == 0.0f && energy.z == 0.0f;
+                        done = !hit || spent || level >= p.depth;
                     }
-                    ++level;
-                    const bool spent = energy.x == 0.0f && energy.y == 0.0f && energy.z == 0.0f;
-                    done = !pend_hit || spent || level >= p.depth;
+                    if (!done) {
+                        walk_begin(p, w, ro, rd);
+                        state = WALK;
+                    } else {
+                        // fs:408-415
+                        const float t = 0.5f * (rd.y + 1.0f);
+                        const float omt = 1.0f - t;
+                        const float sr = energy.x * (omt + 0.5f * t) + emitted.x, sg = energy.y * (omt + 0.7f * t) + emitted.y,
+                                    sb = energy.z * (omt + 1.0f * t) + emitted.z;
+                        fold(sr, sg, sb);
+                        if (remaining <= 0) {
+                            state = DONE;
+                        } else {
+                            ro = ro0; rd = primary_direction(p, rng.fcx, rng.fcy);
+                            energy = V(1.0f, 1.0f, 1.0f); level = 0;
+                            rng.sx = 0.0f;
+                            if (!reuse && p.depth > 0) {
+                                walk_begin(p, w, ro, rd);
+                                state = WALK;
+                            }
+                        }
+                    }
                 }
-                if (!done) {
-                    walk_begin(p, w, ro, rd);
-                    state = WALK;
-                    ++traced; ++rays;
-                    break;
-                }
-                // fs:408-415
-                const float t = 0.5f * (rd.y + 1.0f);
-                const float omt = 1.0f - t;
-                const float sr = energy.x * (omt + 0.5f * t) + emitted.x, sg = energy.y * (omt + 0.7f * t) + emitted.y,
-                            sb = energy.z * (omt + 1.0f * t) + emitted.z;
-                fold(sr, sg, sb, sample_count - remaining);
-                --remaining;
-                sample += p.sample_stride;
-                ro = ro0; rd = rd0; energy = V(1.0f, 1.0f, 1.0f); emitted = V(0.f, 0.f, 0.f); level = 0;
-                rng.samples = (float)sample;
-                rng.sx = 0.0f;
-                if (remaining <= 0) { state = DONE; break; }
-                if (reuse) {
-                    pend_hit = hit0; pend_n = N0; pend_t = t0; pend_id = id0;
-                    ++rays;  // the new sample's camera-ray query, answered by the reused result
-                } else if (p.depth > 0) {
-                    walk_begin(p, w, ro0, rd0);
-                    state = WALK;
-                    ++traced; ++rays;
-                    break;
-                }
+                shaded += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(shades));
             }
+            // queries that set out in this batch: lanes that walk now and did not before it
+            traced += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(state == WALK) & ~walking);
         }
         PT_PHASE_D(tk_shade)
-        const int r = walk_round(p, w, ro, rd, my, state == WALK, wsteps, wrecords);
+        const int r = walk_round(p, w, ro, rd, my, state == WALK, steps, records);
         if (state == WALK) {
             if (r == 2) state = FULL;
-            else if (r == 1) {
-                pend_hit = w.h.id >= 0;
-                pend_t = w.h.t; pend_id = w.h.id;
-                if (pend_hit) pend_n = mesh_normal(p, w.h);
-                state = SHADE;
-            }
+            else if (r == 1) walk_over();
         }
         // (very deep hierarchies) a lane whose own stack is full repeats its query with the per-wave walk
         if (__builtin_amdgcn_ballot_w64(state == FULL)) {
             if (state == FULL) {
-                const Hit h = intersect_bvh<true>(p, ro, rd, s_stack, node_visits, tri_tests);
-                pend_hit = h.id >= 0;
-                pend_t = h.t; pend_id = h.id;
-                if (pend_hit) pend_n = mesh_normal(p, h);
-                state = SHADE;
+                w.h = intersect_bvh<true>(p, ro, rd, s_stack, node_visits, tri_tests);
+                walk_over();
             }
         }
         ++rounds;
         PT_PHASE_D(tk_walk)
     }
-    if (in_window && scratch_slot < 0) {
-        const float alpha = p.accum_mode == 0 ? 1.0f : prev.w + (float)p.num_samples;
-        reinterpret_cast<float4*>(p.dst)[pix] = make_float4(mr, mg, mb, alpha);
-    }
-    const unsigned long long wave_rays = wave_sum(rays), wave_traced = wave_sum(traced), wave_steps = wave_sum(steps) + wsteps, wave_shaded = wave_sum(shaded), wave_records = wrecords;
-    if ((threadIdx.x & 63) == 0 && wave_rays) {
+    if (in_window && scratch_slot < 0) reinterpret_cast<float4*>(p.dst)[pix] = make_float4(mr, mg, mb, malpha);
+    if ((threadIdx.x & 63) == 0 && pixels) {
+        // closest-hit queries as the reference would count them: one per sample for the camera ray plus one per bounce; with reuse
+        // the camera ray of a pixel was evaluated once
+        unsigned long long rays = 0;
+        if (p.depth > 0) rays = reuse ? (unsigned long long)traced - pixels + (unsigned long long)pixels * (unsigned)sample_count : (unsigned long long)traced;
         unsigned long long* counters = p.counters + (size_t)(blockIdx.x % PT_COUNTER_SLOTS) * PT_COUNTER_STRIDE;
-        atomicAdd(&counters[0], wave_rays);
-        atomicAdd(&counters[1], (unsigned long long)__builtin_amdgcn_readfirstlane(batches) * 64ull);  // lane slots of the query batches
-        atomicAdd(&counters[4], wave_traced);
-        if (p.tile_cost) atomicAdd(&p.tile_cost[tile], 2u * __builtin_amdgcn_readfirstlane(rounds) + 8u * __builtin_amdgcn_readfirstlane(batches));
+        atomicAdd(&counters[0], rays);
+        atomicAdd(&counters[1], (unsigned long long)batches * 64ull);  // lane slots of the shade batches
+        atomicAdd(&counters[4], (unsigned long long)traced);
+        if (p.tile_cost) atomicAdd(&p.tile_cost[tile], 2u * rounds + 8u * batches);
         atomicAdd(&counters[2], (unsigned long long)__builtin_amdgcn_readfirstlane(node_visits));
         atomicAdd(&counters[3], (unsigned long long)__builtin_amdgcn_readfirstlane(tri_tests));
-        atomicAdd(&counters[5], wave_steps);
-        atomicAdd(&counters[9], wave_records);
-        if (wave_shaded) atomicAdd(&counters[6], wave_shaded);
+        atomicAdd(&counters[5], (unsigned long long)steps);
+        atomicAdd(&counters[9], (unsigned long long)records);
+        if (shaded) atomicAdd(&counters[6], (unsigned long long)shaded);
 #ifdef PT_V_STATE_COUNT
         atomicAdd(&counters[2], (unsigned long long)st_rounds);       // reported as bvh_node_fetches
         atomicAdd(&counters[3], (unsigned long long)st_walk);         // bvh_triangle_fetches
@@ -1405,6 +1409,7 @@ __global__ __launch_bounds__(64, PT_DECOUPLED_MIN_WAVES) void pt_render_decouple
         atomicAdd(&counters[12], tk_walk);
 #endif
     }
+#undef PT_PHASE_D
 }
 
 // ---- the reference's CPU tracer (PT_PROGRAM_CPU_TRACER) ---------------------------------------------------------------------
