@@ -158,6 +158,75 @@ def test_materials_mode_random_scene_against_oracle(tracer, wave_walk_tracer, ac
     t.program_destroy(prog)
 
 
+def _awkward_meshes():
+    """Layouts that stress the four-child hierarchy with 16-bit boxes: no extent along an axis, a few tiny triangles very far from
+    a dense cluster (a frame step is then larger than the cluster's triangles), every triangle the same, and triangle counts just
+    above what one leaf holds."""
+    rng = np.random.default_rng(23)
+    out = {}
+    g = 24
+    xs, ys = np.meshgrid(np.linspace(-3, 3, g + 1), np.linspace(-2, 2, g + 1))
+    P = np.stack([xs, ys, np.full_like(xs, 7.0)], -1).astype(np.float32)
+    quads = []
+    for j in range(g):
+        for i in range(g):
+            a, b, c, d = P[j, i], P[j, i + 1], P[j + 1, i + 1], P[j + 1, i]
+            quads += [[a, c, b], [a, d, c]]
+    out["flat"] = np.array(quads, np.float32)                                  # z extent 0
+    cluster = (rng.uniform(-1, 1, (600, 1, 3)) * 0.5 + np.array([0, 0, 6.0]) + rng.uniform(-0.05, 0.05, (600, 3, 3))).astype(np.float32)
+    far = (np.array([[4000.0, -3000.0, 9000.0], [-5000.0, 2500.0, 7000.0], [0.0, 6000.0, -8000.0]], np.float32)[:, None, :]
+           + rng.uniform(-0.01, 0.01, (3, 3, 3)).astype(np.float32))
+    big = np.array([[[-40, -6, 2.0], [40, -6, 2.0], [0, -6, 60.0]]], np.float32)   # a floor the cluster's bounce rays hit
+    out["spread"] = np.concatenate([cluster, far, big]).astype(np.float32)
+    one = np.array([[[-1, -1, 6.0], [0, 1, 6.0], [1, -1, 6.0]]], np.float32)
+    out["same"] = np.repeat(one, 37, axis=0)
+    for n in (5, 6, 9):
+        out[f"few{n}"] = (rng.uniform(-1.5, 1.5, (n, 1, 3)) + np.array([0, 0, 6.0]) + rng.uniform(-1.0, 1.0, (n, 3, 3))).astype(np.float32)
+    return out
+
+
+@pytest.mark.parametrize("layout", ["flat", "spread", "same", "few5", "few6", "few9"])
+def test_materials_walk_on_awkward_layouts(tracer, layout):
+    """The decoupled walk over the four-child form against the loop over all triangles, image and ray count bit for bit, and the
+    device-side self-check of the form, on layouts chosen against its box encoding."""
+    from pathtracer_amd import capi
+    tri = _awkward_meshes()[layout]
+    nt = len(tri)
+    rng = np.random.default_rng(5)
+    verts = np.concatenate([tri.reshape(-1, 3), np.zeros((nt * 3, 3), np.float32)], axis=1).astype(np.float32)
+    idx = np.arange(nt * 3, dtype=np.uint32).reshape(-1, 3)
+    mats = np.zeros((6, 4), np.float32)
+    mats[:, :3] = rng.uniform(0.3, 0.9, (6, 3))
+    mats[2, 3] = 4.0
+    mids = rng.integers(0, 6, nt).astype(np.int32)
+    W, H = 120, 72
+    cam = po.camera(60.0, W, H, (0.1, 0.2, 1.0), (0.0, 0.0, 6.0), (0.0, 1.0, 0.0))
+    sph, _ = po.reference_spheres_and_materials()
+    fx = {"width": W, "height": H, "variant": 1, "normal_mode": 1, "depth": 6, "camera": cam, "vertices": verts,
+          "indices": idx, "spheres": sph, "materials": mats, "shading_mode": 1, "material_ids": mids}
+    prog = setup_case(tracer, fx)
+    images, rays = {}, {}
+    for accel in ("brute", "bvh"):
+        if accel == "bvh":
+            tracer.build_accel()
+            tracer.set_accel_mode(capi.ACCEL_BVH)
+        else:
+            tracer.set_accel_mode(capi.ACCEL_BRUTE)
+        tracer.target_clear()
+        tracer.reset_stats()
+        tracer.dispatch(1, 4, 1)
+        tracer.finish()
+        images[accel] = tracer.readback()
+        rays[accel] = tracer.stats()["rays"]
+    assert n_bit_mismatch(images["bvh"], images["brute"]) == 0
+    assert rays["bvh"] == rays["brute"] > W * H * 4
+    compared, bad_id, bad_t = tracer.verify_accel(3)
+    assert compared >= W * H and bad_id == 0 and bad_t == 0
+    tracer.set_accel_mode(capi.ACCEL_AUTO)
+    tracer.set_shading_mode(0)
+    tracer.program_destroy(prog)
+
+
 @pytest.mark.parametrize("limit", [0, 2, 5])
 def test_lane_walk_hands_over_when_its_stack_is_full(limit):
     """The per-lane walk keeps at most 24 pending nodes per lane; a lane that would need more repeats its query with the
