@@ -118,9 +118,9 @@ def render_case(name, scene, cam, W, H, variant, normal_mode, spp_list, crop=Non
     if rad_edit:
         job["edits"] = f"{EDITS}/{rad_edit}.txt"
     if shading_mode:
-        assert variant == po.VARIANT_MESH and normal_mode == po.NORMALS_GEOMETRIC
+        assert variant == po.VARIANT_MESH and (normal_mode == po.NORMALS_GEOMETRIC or shading_mode == 1)
         job.update(rad_base)
-        job["edits"] = f"{EDITS}/{'mesh_materials_unit_geo' if shading_mode == 2 else 'mesh_materials_geo'}.txt"
+        job["edits"] = f"{EDITS}/{'mesh_materials_unit_geo' if shading_mode == 2 else 'mesh_materials' + geo}.txt"
     if not crop:
         job["present_out"] = f"{tmp}/present.u8"   # the reference's copy.fs pass over the final image
     _, dumps, info = harness(job, tmp)
@@ -268,6 +268,22 @@ def unit_materials_case():
     return ("cornell_materials_unit_128", scene, cam, 128, 128, po.VARIANT_MESH, po.NORMALS_GEOMETRIC, [1, 2, 16], None)
 
 
+def monkey_materials_case():
+    """The diffuse/emissive mode on the reference's own mesh with its vertex normals (monkeyhead2.obj, 968 triangles: more than
+    the all-triangles loop is used for, so PT_ACCEL_AUTO renders it through the hierarchy). monkeyhead2.mtl is empty: row 0 is
+    the grey row the MTL rule gives triangles without a material; three more rows (two albedos and an emitter) are dealt to
+    the triangles by index so that every branch of the mode runs."""
+    d, _ = run_obj_dump("monkeyhead2")
+    sph, _ = po.reference_spheres_and_materials()
+    mv, mi = po.mesh_from_obj_arrays(d["v"], d["idx_v"], d["vn"])
+    tab = np.array([[0.5, 0.5, 0.5, 0.0], [0.85, 0.3, 0.2, 0.0], [0.25, 0.7, 0.35, 0.0], [1.0, 0.9, 0.7, 3.0]], np.float32)
+    t = np.arange(len(mi) // 3 if mi.ndim == 1 else len(mi))
+    ids = np.where(t % 11 == 5, 3, t % 3).astype(np.int32)
+    scene = po.Scene(mv, mi, sph, tab, ids)
+    cam = po.camera(60.0, 128, 128, (0, 0, 0), (0, 0, 1), (0, 1, 0))
+    return ("monkey_materials_128", scene, cam, 128, 128, po.VARIANT_MESH, po.NORMALS_VERTEX, [1, 2, 16], None)
+
+
 def case_shading(name):
     return 2 if "materials_unit" in name else (1 if "materials" in name else 0)
 
@@ -276,7 +292,7 @@ def only(names):
     """Generates the named cases and leaves every other fixture as it is (python3 oracle/gen_golden.py --only a,b)."""
     path = f"{GOLD}/generation_report.json"
     report = json.load(open(path)) if os.path.exists(path) else []
-    for (name, sc, cam, W, H, variant, nm, spp, crop) in config4_cases() + [tiny_materials_case(), unit_materials_case()]:
+    for (name, sc, cam, W, H, variant, nm, spp, crop) in config4_cases() + [tiny_materials_case(), unit_materials_case(), monkey_materials_case()]:
         if name not in names:
             continue
         fx, rep = render_case(name, sc, cam, W, H, variant, nm, spp, crop, shading_mode=case_shading(name))
@@ -354,7 +370,7 @@ def main():
         np.savez_compressed(f"{GOLD}/case_{name}.npz", **fx)
         report.append(rep)
 
-    for (name, sc, cam, W, H, variant, nm, spp, crop) in config4_cases() + [tiny_materials_case(), unit_materials_case()]:
+    for (name, sc, cam, W, H, variant, nm, spp, crop) in config4_cases() + [tiny_materials_case(), unit_materials_case(), monkey_materials_case()]:
         fx, rep = render_case(name, sc, cam, W, H, variant, nm, spp, crop, shading_mode=case_shading(name))
         np.savez_compressed(f"{GOLD}/case_{name}.npz", **fx)
         report.append(rep)

@@ -259,7 +259,7 @@ def test_lane_walk_hands_over_when_its_stack_is_full(limit):
         t.close()
 
 
-@pytest.mark.parametrize("name", ["cornell_materials_128", "cornell_materials_unit_128", "cornell_materials_tiny_96"])
+@pytest.mark.parametrize("name", ["cornell_materials_128", "cornell_materials_unit_128", "cornell_materials_tiny_96", "monkey_materials_128"])
 @pytest.mark.parametrize("walk", ["lane", "lane_in_step", "wave"])
 def test_materials_golden_through_bvh(tracer, wave_walk_tracer, in_step_walk_tracer, walk, name):
     """The llvmpipe goldens of the diffuse/emissive modes, traced through the LBVH with absolute boxes by each of its three
@@ -745,13 +745,14 @@ def test_row_interleave_partition_is_exact(tracer, block, count):
     t.program_destroy(prog)
 
 
-def test_sample_split_over_eight_at_full_size():
-    """Configuration C3's partition at its own size: monkeyhead2 at 1920x1080, 1024 samples as eight residue classes of 128
-    (what eight GPUs render), summed and scaled, against the sequential running mean of the same 1024 samples: equal to
+@pytest.mark.parametrize("workload", ["monkeyhead2", "suzanne"])
+def test_sample_split_over_eight_at_full_size(workload):
+    """Configuration C3's partition at its own size: monkeyhead2 and suzanne at 1920x1080, 1024 samples as eight residue classes
+    of 128 (what eight GPUs render), summed and scaled, against the sequential running mean of the same 1024 samples: equal to
     rounding (|difference| < 2e-6 on values in [0, 1]); ray counts of the parts add up to the whole."""
     from pathtracer_amd import Tracer, capi
     from pathtracer_amd.scenes import SceneData
-    scene = SceneData("monkeyhead2")
+    scene = SceneData(workload)
     t = Tracer(0)
     try:
         scene.upload(t)
@@ -772,6 +773,46 @@ def test_sample_split_over_eight_at_full_size():
         assert t.stats()["rays"] == rays
         assert total.dtype == np.float32
         assert np.abs(total * np.float32(1.0 / 1024.0) - mean).max() < 2e-6
+    finally:
+        t.close()
+
+
+def test_c5_at_its_full_length():
+    """Configuration C5 at its own size and length: the ~1M-triangle instanced scene at 3840x2160 with 4096 samples. One dispatch
+    of 4096 (probe, work list, split tiles, fold) against sixteen dispatches of 256: the same image bit for bit and the same ray
+    count; then the window of a 64x64 crop with all 4096 samples through the direction grid and through the hierarchy walk: the
+    same bits again, and equal to the crop of the full frame."""
+    from pathtracer_amd import Tracer, capi
+    from pathtracer_amd.scenes import SceneData
+    scene = SceneData("instanced")
+    t = Tracer(0)
+    try:
+        scene.upload(t)
+        W, H = scene.width, scene.height
+        t.target_create(W, H)
+        t.dispatch(1, 4096, 1)
+        t.finish()
+        whole = t.readback().copy()
+        rays = t.stats()["rays"]
+        t.reset_stats()
+        t.target_clear()
+        for k in range(16):
+            t.dispatch(1 + 256 * k, 256, 1)
+        t.finish()
+        assert n_bit_mismatch(t.readback(), whole) == 0
+        assert t.stats()["rays"] == rays > W * H * 4096
+        x0, y0 = 1900, 1000
+        crops = {}
+        for accel in (capi.ACCEL_GRID, capi.ACCEL_BVH):
+            t.set_accel_mode(accel)
+            t.set_window(x0, y0, 64, 64)
+            t.target_clear()
+            t.dispatch(1, 4096, 1)
+            t.finish()
+            crops[accel] = t.readback()[y0:y0 + 64, x0:x0 + 64].copy()
+        assert n_bit_mismatch(crops[capi.ACCEL_GRID], crops[capi.ACCEL_BVH]) == 0
+        assert n_bit_mismatch(crops[capi.ACCEL_GRID], whole[y0:y0 + 64, x0:x0 + 64]) == 0
+        assert (crops[capi.ACCEL_GRID][..., :3] != crops[capi.ACCEL_GRID][0, 0, :3]).any()   # the crop is not all one colour
     finally:
         t.close()
 
