@@ -492,8 +492,11 @@ def main():
     trace("warm-up done")
     tracer.reset_stats()
     t0 = time.perf_counter()
+    issue_ms = []   # how long each step's calls held the host (a dispatch that rebuilds its work list reads two counters back)
     for _ in range(args.steps):
+        ts = time.perf_counter()
         step()
+        issue_ms.append((time.perf_counter() - ts) * 1e3)
     fence()
     elapsed = time.perf_counter() - t0
     trace("timed steps done")
@@ -567,6 +570,11 @@ def main():
                                                                            if tile_split else f"sample split over {world} GPUs + RCCL all-reduce of the sums" +
                                                                            (", overlapped with the next step's rendering" if merger is not None else ""))},
             "value_evaluated": traced / elapsed * 1e-6,
+            "host_issue_ms_per_step": {"median": float(np.median(issue_ms)), "max": float(np.max(issue_ms)),
+                                       "note": "time this rank's host spent inside each step's calls (dispatch and merge submission). With the "
+                                               "library's timing switched on, as here, a dispatch first collects the previous dispatch's events, so "
+                                               "the host runs one step ahead of the device and the median is the device's step time; what matters is "
+                                               "how far the maximum lies above it (a dispatch that rebuilds its work list also waits for two counters)"},
             "rays_definition": "value: closest-hit queries as the reference counts them, one per bounce-loop iteration of every sample "
                                "(PathTracer.cpp:947). The shader has no pixel jitter, so the first query of every sample of a pixel "
                                "is the same; it is evaluated once per dispatch and pixel and reused (bit-identical image). "

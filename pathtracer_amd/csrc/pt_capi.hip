@@ -176,6 +176,7 @@ struct PtContext {
         int32_t num_triangles, win[4], rows[3], normal_mode, accel_mode;
         uint32_t program;
     } primary_cache_key{};
+    int sched_sort = 1;             // PT_SCHED_SORT=0: the work list keeps its split but is not ordered by cost
     int sched_mode = 2;             // 0 raster order, 1 cost-ordered tiles, 2 cost-ordered items with heavy tiles split by samples
     int32_t fail_grid_alloc = 0, grid_allocs = 0;  // PT_FAIL_GRID_ALLOC=k (testing): the k-th allocation of the grid build fails
     bool no_alloc = false;          // inside pt_dispatch_static: whatever would allocate device or host memory fails instead
@@ -635,6 +636,7 @@ PtStatus pt_create(int32_t device, PtContext** out_ctx) {
     else if (sched && sched[0] == 't') ctx->sched_mode = 1;
     ctx->wave_slots = prop.multiProcessorCount * 4 * 8;
 
+    if (const char* g = getenv("PT_SCHED_SORT")) ctx->sched_sort = atoi(g);
     if (const char* g = getenv("PT_AUTO_GRID")) ctx->auto_grid = g[0] != '0';
     if (const char* g = getenv("PT_PRIMARY_CACHE")) ctx->primary_cache_enabled = g[0] != '0';
     if (const char* g = getenv("PT_GRID_QUEUE")) ctx->grid_queue_override = atoi(g);
@@ -1080,7 +1082,7 @@ PtStatus dispatch_range(PtContext* ctx, int32_t first_sample, int32_t num_sample
                 for (;;) {
                     const int max_split = splitting ? (int)(factor * (float)ctx->wave_slots) : 0;
                     PT_HIP_TRY(pt_launch_schedule_items(ctx->d_tile_cost, ctx->d_items, ctx->d_sched_counts, ctx->d_split_tiles, ctx->d_sched_tmp, tiles,
-                                                        num_samples, max_split, ctx->stream));
+                                                        num_samples, max_split, ctx->sched_sort, ctx->stream));
                     if (!splitting) {  // single-sample dispatches (frame loops): whole tiles in cost order, nothing to read back
                         c[0] = (uint32_t)tiles; c[1] = 0;
                         break;
@@ -1286,7 +1288,7 @@ PtStatus pt_dispatch_static(PtContext* ctx, int32_t first_sample, int32_t num_sa
                                                       : ((p.bvh_nodes || p.bvh_nodes_abs) ? 4.0f : 1.0f);
         size_t max_split = std::min<size_t>((size_t)(factor * (float)ctx->wave_slots), PT_STATIC_MAX_SPLIT);
         max_split = std::min(max_split, kStaticSampleBytes / slot_bytes);  // as many split tiles as the array can park
-        PT_HIP_TRY(pt_launch_schedule_items(cost, items, counts, split_tiles, tmp, (int)tiles, rest, (int)max_split, ctx->stream));
+        PT_HIP_TRY(pt_launch_schedule_items(cost, items, counts, split_tiles, tmp, (int)tiles, rest, (int)max_split, ctx->sched_sort, ctx->stream));
         p.items = items;
         p.sched_counts = counts;
         p.split_tiles = split_tiles;

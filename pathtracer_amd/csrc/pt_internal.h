@@ -227,9 +227,10 @@ hipError_t pt_launch_present(const float* img, size_t num_pixels, uint32_t* out_
 // Work list for the next dispatch from the per-tile costs of the previous one: tiles whose cost exceeds
 // total / max_split_tiles are split into several items (at most num_samples), items ordered most expensive first.
 // Always: item count <= num_tiles + max_split_tiles and split tiles <= max_split_tiles. tile_cost is only read.
+// sort = 0 keeps the split but leaves the list in tile order.
 // sched_counts <- {items, split tiles}.
 hipError_t pt_launch_schedule_items(const uint32_t* tile_cost, PtWorkItem* items, uint32_t* sched_counts, uint32_t* split_tiles, uint32_t* sched_tmp,
-                                    int num_tiles, int num_samples, int max_split_tiles, hipStream_t stream);
+                                    int num_tiles, int num_samples, int max_split_tiles, int sort, hipStream_t stream);
 #define PT_SCHED_TMP_WORDS (4 + 64 * 64)  // scratch of the scheduler's launches: total cost, per-workgroup bucket counts
 hipError_t pt_launch_primary(const PtKernelParams& p, int program_kind, hipStream_t stream);
 // every camera ray (and p.verify_bounces generations of bounce rays) through the structure `p` selects AND through the loop

@@ -2041,9 +2041,8 @@ hipError_t pt_launch_arith_selftest(unsigned long long* bad, hipStream_t stream)
 }
 
 hipError_t pt_launch_schedule_items(const uint32_t* tile_cost, PtWorkItem* items, uint32_t* sched_counts, uint32_t* split_tiles, uint32_t* sched_tmp,
-                                    int num_tiles, int num_samples, int max_split_tiles, hipStream_t stream) {
+                                    int num_tiles, int num_samples, int max_split_tiles, int sort, hipStream_t stream) {
     if (num_tiles <= 0) return hipSuccess;
-    static const int sort = getenv("PT_SCHED_SORT") ? atoi(getenv("PT_SCHED_SORT")) : 1;
     hipError_t e = hipMemsetAsync(sched_tmp, 0, 4 * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     const dim3 grid(PT_SCHED_BLOCKS), block(PT_SCHED_THREADS);

@@ -130,15 +130,15 @@ bool Shader::createProgram(int signature) {
     const Stage s = getStage();
     if (s == STAGE_PATHTRACE_WORLD || s == STAGE_PATHTRACE_MESH) {
         if (!g_context) {
-            std::cout << "Shader::createProgram: no device context (call Shader::SetContext)" << std::endl;
+            std::cerr << "Shader::createProgram: no device context (call Shader::SetContext)" << std::endl;
             return true;
         }
         uint32_t handle = 0;
         const PtStatus st = pt_program_create(g_context, s == STAGE_PATHTRACE_MESH ? PT_PROGRAM_MESH : PT_PROGRAM_WORLD, &handle);
-        if (st != PT_OK) std::cout << pt_last_error() << std::endl;
+        if (st != PT_OK) std::cerr << pt_last_error() << std::endl;
         m_ProgramObject = handle;
     }
-    // Like the reference, failures are reported on stdout and the call still returns true; check getProgram() != 0.
+    // Like the reference, the call returns true whatever happened; failures go to stderr, and getProgram() stays 0.
     return true;
 }
 
