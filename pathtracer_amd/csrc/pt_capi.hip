@@ -124,6 +124,9 @@ struct PtContext {
     int32_t grid_queue_override = 0;  // PT_GRID_QUEUE=n (testing): capacity of the grid build's queue of large jobs
     bool grid_res_reduced = false;  // the preferred resolution gave lists too long for this mesh
     uint64_t grid_entries = 0;
+    bool grid_use_occ = false;       // the block bits are worth a look: a quarter of the blocks or more are empty (build_grid)
+    uint32_t* d_grid_occ_flag = nullptr;  // ... and the view's queries mostly miss (device word, kept up to date with the work list)
+    int grid_occ_override = -1;      // PT_GRID_OCC=0/1 (experiments)
     unsigned long long* d_grid_count_scratch = nullptr;   // scratch of the grid's count pass and its three-word summary
     unsigned long long* h_grid_summary = nullptr;    // pinned host copy of the summary
 
@@ -267,7 +270,7 @@ void free_bvh(PtContext* ctx) {
 
 void free_grid(PtContext* ctx) {
     PtGridBuild& g = ctx->grid;
-    void* ptrs[] = {g.cell_count, g.cell_start, g.cells, g.list, g.scan_tmp, g.big_jobs, g.big_cells, g.big_count};
+    void* ptrs[] = {g.cell_count, g.cell_start, g.cells, g.list, g.occ, g.scan_tmp, g.big_jobs, g.big_cells, g.big_count};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     g = PtGridBuild{};
@@ -319,6 +322,7 @@ PtStatus build_grid(PtContext* ctx) {
             hipError_t e = grid_alloc(ctx, &g.cell_count, (cells + 1) * sizeof(uint32_t));
             if (e == hipSuccess) e = grid_alloc(ctx, &g.cell_start, (cells + 1) * sizeof(uint32_t));
             if (e == hipSuccess) e = grid_alloc(ctx, &g.cells, (cells + 1) * sizeof(uint32_t));
+            if (e == hipSuccess) e = grid_alloc(ctx, &g.occ, PT_GRID_OCC_WORDS(res) * sizeof(uint32_t));
             if (e == hipSuccess) e = grid_alloc(ctx, &g.scan_tmp, g.scan_tmp_bytes ? g.scan_tmp_bytes : 16);
             if (e == hipSuccess) e = grid_alloc(ctx, &g.big_jobs, (size_t)g.big_capacity * sizeof(uint32_t));
             if (e == hipSuccess) e = grid_alloc(ctx, &g.big_cells, (size_t)g.big_capacity * sizeof(uint32_t));
@@ -332,7 +336,7 @@ PtStatus build_grid(PtContext* ctx) {
         // the count pass also sums the bound and stops short of the large jobs when it is exceeded
         unsigned long long* summary = ctx->d_grid_count_scratch + 2 * PT_GRID_BOUND_SLOTS;
         PT_HIP_TRY(pt_grid_count(g, ctx->d_tris, ctx->num_triangles, ctx->d_grid_count_scratch, summary, ctx->stream));
-        PT_HIP_TRY(hipMemcpyAsync(ctx->h_grid_summary, summary, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+        PT_HIP_TRY(hipMemcpyAsync(ctx->h_grid_summary, summary, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
         PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
         const unsigned long long bound = ctx->h_grid_summary[0];
         entries = (uint32_t)std::min<unsigned long long>(ctx->h_grid_summary[1], 0xffffffffull);
@@ -351,6 +355,14 @@ PtStatus build_grid(PtContext* ctx) {
         g.list_capacity = cap;
     }
     PT_HIP_TRY(pt_grid_fill(g, ctx->d_tris, ctx->num_triangles, ctx->stream));
+    {
+        // Queries consult the block bits where they can end many of them early: a quarter of the blocks empty, or more.
+        // (Cornell, a closed box: none, and the look-up would only lengthen every query.)
+        const unsigned long long edge = PT_GRID_OCC_EDGE(g.res), blocks = 6ull * edge * edge;
+        ctx->grid_use_occ = ctx->grid_occ_override >= 0 ? ctx->grid_occ_override != 0 : 4ull * ctx->h_grid_summary[3] >= blocks;
+        // until the view's own statistics say otherwise (PT_GRID_OCC=1 pins it)
+        PT_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ctx->d_grid_occ_flag), 1u, 1, ctx->stream));
+    }
     ctx->grid_entries = entries;
     ctx->grid_built = true;
     return PT_OK;
@@ -514,6 +526,8 @@ PtStatus fill_params(PtContext* ctx, PtKernelParams* p, const Program** prog_out
         if (use_grid) {
             p->grid_cells = ctx->grid.cells;
             p->grid_list = ctx->grid.list;
+            p->grid_occ = ctx->grid_use_occ ? ctx->grid.occ : nullptr;
+            p->grid_occ_flag = ctx->d_grid_occ_flag;
             p->grid_tris = ctx->d_tris_grid;
             p->grid_res = ctx->grid.res;
         } else if (is_materials(ctx->shading_mode)) {
@@ -620,6 +634,7 @@ PtStatus pt_create(int32_t device, PtContext** out_ctx) {
     if (err == hipSuccess) err = hipMalloc(&ctx->d_counters, kCounterBytes);
     if (err == hipSuccess) err = hipMemsetAsync(ctx->d_counters, 0, kCounterBytes, ctx->own_stream);
     if (err == hipSuccess) err = hipStreamSynchronize(ctx->own_stream);
+    if (err == hipSuccess) err = hipMalloc(&ctx->d_grid_occ_flag, 256);
     if (err == hipSuccess) err = hipMalloc(&ctx->d_spheres, 40 * sizeof(float));
     if (err == hipSuccess) err = hipMalloc(&ctx->d_sphere_recs, 80 * sizeof(float));
     if (err == hipSuccess) err = hipEventCreate(&ctx->ev_start);
@@ -639,6 +654,7 @@ PtStatus pt_create(int32_t device, PtContext** out_ctx) {
     if (const char* g = getenv("PT_SCHED_SORT")) ctx->sched_sort = atoi(g);
     if (const char* g = getenv("PT_AUTO_GRID")) ctx->auto_grid = g[0] != '0';
     if (const char* g = getenv("PT_PRIMARY_CACHE")) ctx->primary_cache_enabled = g[0] != '0';
+    if (const char* g = getenv("PT_GRID_OCC")) ctx->grid_occ_override = atoi(g) != 0;
     if (const char* g = getenv("PT_GRID_QUEUE")) ctx->grid_queue_override = atoi(g);
     if (const char* g = getenv("PT_FAIL_GRID_ALLOC")) ctx->fail_grid_alloc = atoi(g);
     if (const char* g = getenv("PT_GRID_RES")) ctx->grid_res_override = std::min(atoi(g), 8192);  // cell indices stay far below 2^32
@@ -662,6 +678,7 @@ PtStatus pt_destroy(PtContext* ctx) {
     if (ctx->d_grid_count_scratch) (void)hipFree(ctx->d_grid_count_scratch);
     if (ctx->h_grid_summary) (void)hipHostFree(ctx->h_grid_summary);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    if (ctx->d_grid_occ_flag) (void)hipFree(ctx->d_grid_occ_flag);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -1075,6 +1092,9 @@ PtStatus dispatch_range(PtContext* ctx, int32_t first_sample, int32_t num_sample
             const bool reuse = ctx->list_valid && ctx->list_samples == num_samples && ctx->list_base_factor == base_factor &&
                                ctx->list_entry_bytes == entry_bytes && ctx->list_age < 16 && ctx->cost_samples < 2 * ctx->list_basis;
             if (!reuse) {
+                // (direction grid: whether its queries look at the block bits first follows the view's statistics so far)
+                if (p.grid_occ && ctx->grid_occ_override < 0)
+                    PT_HIP_TRY(pt_launch_grid_occ_flag(ctx->d_counters, (unsigned long long)ctx->samples, ctx->d_grid_occ_flag, ctx->stream));
                 // The scheduler's counts are read back (a short stall, at rebuilds only): they size the launches and the
                 // scratch exactly, and they tell whether this view wants the eager split.
                 float factor = (ctx->concentrated && ctx->split_factor < 0.f) ? eager_factor : base_factor;
@@ -1288,6 +1308,8 @@ PtStatus pt_dispatch_static(PtContext* ctx, int32_t first_sample, int32_t num_sa
                                                       : ((p.bvh_nodes || p.bvh_nodes_abs) ? 4.0f : 1.0f);
         size_t max_split = std::min<size_t>((size_t)(factor * (float)ctx->wave_slots), PT_STATIC_MAX_SPLIT);
         max_split = std::min(max_split, kStaticSampleBytes / slot_bytes);  // as many split tiles as the array can park
+        if (p.grid_occ && ctx->grid_occ_override < 0)
+            PT_HIP_TRY(pt_launch_grid_occ_flag(ctx->d_counters, (unsigned long long)ctx->samples, ctx->d_grid_occ_flag, ctx->stream));
         PT_HIP_TRY(pt_launch_schedule_items(cost, items, counts, split_tiles, tmp, (int)tiles, rest, (int)max_split, ctx->sched_sort, ctx->stream));
         p.items = items;
         p.sched_counts = counts;

@@ -322,6 +322,34 @@ __global__ __launch_bounds__(PT_GRID_BOUND_SLOTS) void grid_summary(const unsign
     }
 }
 
+// After the count pass: one bit per 4x4 block of cells, set when any cell of the block was entered by a triangle; *empty += the
+// blocks with none. A query looks at the bit first where much of the sphere of directions is empty (open scenes: most bounce rays
+// leave): the bits of a whole face fit in the caches next to the compute units, a cell word of a fine grid costs a line from
+// the fabric. One thread per block, a wave writes its 64 bits as two words.
+__global__ __launch_bounds__(256) void grid_occupancy(const uint32_t* __restrict__ cell_count, int res, uint32_t* __restrict__ occ,
+                                                      unsigned long long* __restrict__ empty) {
+    const int edge = PT_GRID_OCC_EDGE(res);
+    const uint32_t blocks = 6u * (uint32_t)edge * (uint32_t)edge;
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    bool any = false;
+    if (b < blocks) {
+        const int face = (int)(b / (uint32_t)(edge * edge)), rem = (int)(b % (uint32_t)(edge * edge));
+        const int bv = rem / edge, bu = rem % edge;
+        for (int dv = 0; dv < 4; ++dv)
+            for (int du = 0; du < 4; ++du) {
+                const int iu = 4 * bu + du, iv = 4 * bv + dv;
+                if (iu < res && iv < res) any = any || cell_count[((size_t)face * res + iv) * res + iu] != 0u;
+            }
+    }
+    const unsigned long long bits = __ballot(any), valid = __ballot(b < blocks);
+    if ((threadIdx.x & 63) == 0 && valid) {
+        occ[(b >> 6) * 2] = (uint32_t)bits;
+        occ[(b >> 6) * 2 + 1] = (uint32_t)(bits >> 32);
+        const unsigned none = (unsigned)__builtin_popcountll(valid & ~bits);
+        if (none) atomicAdd(empty, (unsigned long long)none);
+    }
+}
+
 // Start of a pass, in one launch instead of three fills: the cell counters (fill cursors) to zero, the queue length to
 // zero; count pass: the bound slots to zero; fill pass: every cell word to PT_GRID_EMPTY. words = 6*res*res + 1.
 template <bool COUNT>
@@ -339,6 +367,7 @@ __global__ __launch_bounds__(256) void grid_reset(uint32_t* __restrict__ cell_co
     }
     if (i == 0) *big_count = 0u;
     if (COUNT && i < 2 * PT_GRID_BOUND_SLOTS) bound[i] = 0ull;
+    if (COUNT && i == 0) bound[2 * PT_GRID_BOUND_SLOTS + 3] = 0ull;  // the summary's count of empty blocks (grid_occupancy adds to it)
 }
 
 template <bool COUNT>
@@ -367,6 +396,10 @@ hipError_t pt_grid_count(const PtGridBuild& g, const float* tris, int32_t n, uns
     const size_t cells = (size_t)6 * g.res * g.res;
     hipError_t e = bin_all<true>(g, tris, n, slots, stream);
     if (e != hipSuccess) return e;
+    {
+        const uint32_t edge = (uint32_t)PT_GRID_OCC_EDGE(g.res), blocks = 6u * edge * edge;
+        hipLaunchKernelGGL(grid_occupancy, dim3((blocks + 255) / 256), dim3(256), 0, stream, g.cell_count, g.res, g.occ, summary + 3);
+    }
     // list space of every cell (none for cells with fewer than two triangles)
     size_t bytes = g.scan_tmp_bytes;
     hipcub::TransformInputIterator<uint32_t, ListNeed, const uint32_t*> need(g.cell_count, ListNeed());

@@ -97,6 +97,7 @@ struct PtGridBuild {
     uint32_t* cell_start;   // 6*res*res + 1: prefix sums of the list space of the cells (build only)
     uint32_t* cells;        // 6*res*res + 1: what a query reads (PT_GRID_EMPTY, the one triangle, or 1<<31 | list position)
     uint32_t* list;         // triangle indices
+    uint32_t* occ;          // one bit per 4x4 block of cells: some cell of the block holds a triangle (PT_GRID_OCC_WORDS(res) words)
     size_t list_capacity;   // entries
     void* scan_tmp;
     size_t scan_tmp_bytes;
@@ -108,8 +109,10 @@ struct PtGridBuild {
 size_t pt_grid_scan_temp_bytes(size_t cells);
 // Counts the entries of every cell; afterwards cell_start[6*res*res] = the list length needed and summary[0..2] = an upper
 // bound of the list length (bounding-box cells of every triangle and face), the (cell, triangle) entries, the list words
-// needed. A bound of PT_GRID_MAX_LIST_BOUND or more means the resolution is too fine for this mesh: the large jobs were
+// needed, summary[3] = the 4x4 blocks of cells that hold no triangle at all (g.occ is written too). A bound of PT_GRID_MAX_LIST_BOUND or more means the resolution is too fine for this mesh: the large jobs were
 // then not walked and the counts are not usable. slots: 2 * PT_GRID_BOUND_SLOTS words of device scratch.
+#define PT_GRID_OCC_EDGE(res) (((res) + 3) / 4)
+#define PT_GRID_OCC_WORDS(res) (((size_t)6 * PT_GRID_OCC_EDGE(res) * PT_GRID_OCC_EDGE(res) + 63) / 64 * 2)
 #define PT_GRID_MAX_LIST_BOUND (1ull << 30)
 #define PT_GRID_BOUND_SLOTS 256
 hipError_t pt_grid_count(const PtGridBuild& g, const float* tris, int32_t n, unsigned long long* slots, unsigned long long* summary,
@@ -165,6 +168,8 @@ struct PtKernelParams {
     const float* cull;                  // num_triangles x PT_CULL_FLOATS, or null = no wave-level culling
     const uint32_t* grid_cells;         // direction grid: one word per cell (see PtGridBuild::cells), or null
     const uint32_t* grid_list;          // triangle indices of the cells with two or more (last one of a cell: top bit set)
+    const uint32_t* grid_occ;           // one bit per 4x4 block of cells (0 = no triangle in the block), or null = not consulted
+    const uint32_t* grid_occ_flag;      // device word: nonzero = queries look at grid_occ first (pt_launch_grid_occ_flag keeps it)
     const float* grid_tris;             // per triangle: e1, e2, ap, r, e2r, geometric normal (origin-relative)
     int32_t grid_res;
     const uint32_t* live_count;         // device scalar: records in `tris` when it is the compacted array; null = num_triangles
@@ -232,6 +237,8 @@ hipError_t pt_launch_present(const float* img, size_t num_pixels, uint32_t* out_
 hipError_t pt_launch_schedule_items(const uint32_t* tile_cost, PtWorkItem* items, uint32_t* sched_counts, uint32_t* split_tiles, uint32_t* sched_tmp,
                                     int num_tiles, int num_samples, int max_split_tiles, int sort, hipStream_t stream);
 #define PT_SCHED_TMP_WORDS (4 + 64 * 64)  // scratch of the scheduler's launches: total cost, per-workgroup bucket counts
+// *flag <- whether the direction grid's queries should consult the block bits, from the statistics counters (see the kernel)
+hipError_t pt_launch_grid_occ_flag(const unsigned long long* counters, unsigned long long samples, uint32_t* flag, hipStream_t stream);
 hipError_t pt_launch_primary(const PtKernelParams& p, int program_kind, hipStream_t stream);
 // every camera ray (and p.verify_bounces generations of bounce rays) through the structure `p` selects AND through the loop
 // over all of p.verify_tris; counts into p.verify_out. hipErrorInvalidValue when `p` selects no structure to check.

@@ -581,7 +581,7 @@ __device__ __forceinline__ Hit intersect_bvh_lanes(const PtKernelParams& p, v3 r
 // lane walks its own list (lanes of a wave look in different cells), records come through per-lane vector loads; the
 // index of the next entry is fetched while the current triangle is tested. Same exact test, explicit lowest-index rule.
 // `gn` <- the accepted triangle's geometric normal, which travels in its record.
-__device__ __forceinline__ Hit intersect_grid(const PtKernelParams& p, v3 rd, unsigned& tests, v3& gn) {
+__device__ __forceinline__ Hit intersect_grid(const PtKernelParams& p, v3 rd, unsigned& tests, v3& gn, bool use_occ) {
     Hit h;
     h.t = 1.0e38f; h.id = -1; h.u = 0.f; h.v = 0.f; h.ood = 0.f;
     const float ax = __builtin_fabsf(rd.x), ay = __builtin_fabsf(rd.y), az = __builtin_fabsf(rd.z);
@@ -601,6 +601,13 @@ __device__ __forceinline__ Hit intersect_grid(const PtKernelParams& p, v3 rd, un
     iv = iv < 0 ? 0 : (iv >= res ? res - 1 : iv);
     // < 6 * 2048^2; both factors of either product are below 2^24, so the full-rate 24-bit multiply is exact
     const uint32_t cell = __umul24(__umul24((uint32_t)face, (uint32_t)res) + (uint32_t)iv, (uint32_t)res) + (uint32_t)iu;
+    // Open scenes: one bit per 4x4 block of cells says whether anything lies that way at all (read from a table small enough to
+    // stay next to the compute units; the cell word of a fine grid comes from the fabric).
+    if (use_occ) {  // (wave-uniform)
+        const uint32_t edge = (uint32_t)PT_GRID_OCC_EDGE(res);
+        const uint32_t blk = __umul24(__umul24((uint32_t)face, edge) + ((uint32_t)iv >> 2), edge) + ((uint32_t)iu >> 2);
+        if (!((p.grid_occ[blk >> 5] >> (blk & 31u)) & 1u)) return h;
+    }
     // One word per cell: empty, the cell's only triangle (then the record is the very next fetch), or the position of its
     // list, whose last entry carries the top bit.
     uint32_t entry = p.grid_cells[cell];
@@ -837,6 +844,8 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
     unsigned loop_full = 0;                   // per WAVE (all-triangles loop): tests that went past the wave-uniform back-face skip
     unsigned shaded = 0;                      // per LANE: hits shaded
 
+    // direction grid: whether queries look at the block bits first (they exist, and the view's queries mostly miss)
+    const bool use_occ = KIND == 4 && p.grid_occ != nullptr && *(const kuint32*)p.grid_occ_flag != 0u;
     CullRec cull0;
     if (KIND == 3) cull0 = load_cull(reinterpret_cast<const float4*>(p.cull), threadIdx.x & 63, p.num_triangles);
 
@@ -856,7 +865,7 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
                 h = intersect_bvh_lanes(p, o, d, s_lane_stack[threadIdx.x >> 6], overflow, lane_tests);
                 if (overflow) h = intersect_bvh<true>(p, o, d, s_stack[threadIdx.x >> 6], node_visits, tri_tests);
             }
-            else h = intersect_grid(p, d, lane_tests, n);
+            else h = intersect_grid(p, d, lane_tests, n, use_occ);
         }
         const bool hit = want && h.id >= 0;
         if (hit && KIND != 0 && !(KIND == 4 && p.normal_mode != 0)) n = mesh_normal(p, h);  // (the grid's records hold the geometric normal)
@@ -1581,7 +1590,7 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_primary_kernel(const PtKer
     if (KIND == 1) h = intersect_mesh(p.tris, live_triangles(p), rd, tt);
     if (KIND == 2) h = intersect_bvh<false>(p, ro, rd, s_stack[threadIdx.x >> 6], nv, tt);
     if (KIND == 3) h = intersect_mesh_culled(p, rd, in_window, load_cull(reinterpret_cast<const float4*>(p.cull), threadIdx.x & 63, p.num_triangles), tt);
-    if (KIND == 4) h = intersect_grid(p, rd, tt, N);
+    if (KIND == 4) h = intersect_grid(p, rd, tt, N, p.grid_occ != nullptr);
     if (!in_window) return;
     if (p.out_ids) p.out_ids[pix] = h.id;
     if (p.out_t) p.out_t[pix] = h.t;
@@ -1626,7 +1635,7 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_verify_kernel(const PtKern
                 do { r = walk_round(p, w, ro, rd, my, true, nv, tt); } while (r == 0);
                 b = w.h;
                 if (r == 2) b = intersect_bvh<true>(p, ro, rd, s_stack[threadIdx.x >> 6], nv, tt);
-            } else b = intersect_grid(p, rd, tt, gn);
+            } else b = intersect_grid(p, rd, tt, gn, p.grid_occ != nullptr);  // (the block bits are checked whenever they exist)
             ++compared;
             bad_id += a.id != b.id ? 1u : 0u;
             bad_t += __float_as_uint(a.t) != __float_as_uint(b.t) ? 1u : 0u;
@@ -2051,6 +2060,27 @@ hipError_t pt_launch_schedule_items(const uint32_t* tile_cost, PtWorkItem* items
     hipLaunchKernelGGL(pt_sched_offsets_kernel, dim3(1), dim3(64), 0, stream, sched_tmp, sched_counts);
     hipLaunchKernelGGL(pt_sched_scatter_kernel, grid, block, 0, stream, tile_cost, num_tiles, num_samples, max_split_tiles, sort, sched_tmp, items,
                        sched_counts, split_tiles);
+    return hipGetLastError();
+}
+
+// flag <- 1 when the queries counted so far end the sample at the first or second query on average (an open scene: most
+// bounce rays leave), 0 when paths are longer (a closed scene); unchanged while fewer than 65,536 samples are counted.
+__global__ __launch_bounds__(PT_COUNTER_SLOTS) void pt_grid_occ_flag_kernel(const unsigned long long* __restrict__ counters, unsigned long long samples,
+                                                                            uint32_t* __restrict__ flag) {
+    __shared__ unsigned long long part[PT_COUNTER_SLOTS / 64];
+    unsigned long long rays = counters[(size_t)threadIdx.x * PT_COUNTER_STRIDE];
+    rays = wave_sum(rays);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = rays;
+    __syncthreads();
+    if (threadIdx.x == 0 && samples >= 65536ull) {
+        unsigned long long total = 0;
+        for (int w = 0; w < PT_COUNTER_SLOTS / 64; ++w) total += part[w];
+        *flag = total < 2ull * samples ? 1u : 0u;
+    }
+}
+
+hipError_t pt_launch_grid_occ_flag(const unsigned long long* counters, unsigned long long samples, uint32_t* flag, hipStream_t stream) {
+    hipLaunchKernelGGL(pt_grid_occ_flag_kernel, dim3(1), dim3(PT_COUNTER_SLOTS), 0, stream, counters, samples, flag);
     return hipGetLastError();
 }
 

@@ -378,6 +378,41 @@ def _verify(t, accel, bounces):
     return compared, bad_id, bad_t
 
 
+@pytest.mark.parametrize("workload,size", [("cornell", (480, 270)), ("suzanne", (480, 270)), ("instanced", (960, 540))])
+def test_block_bits_of_the_direction_grid_change_nothing(workload, size):
+    """The grid's bit per 4x4 block of cells lets a query end before it fetches its cell word. Consulted always (PT_GRID_OCC=1),
+    never (=0) or as the view's statistics decide (the default): the same image and the same ray count, and the self-check (which
+    looks at the bits whenever they exist) finds every query equal to the loop over all triangles."""
+    import os
+    from pathtracer_amd import Tracer, capi
+    from pathtracer_amd.scenes import SceneData
+    scene = SceneData(workload, *size)
+    images, rays = {}, {}
+    for mode in ("0", "1", None):
+        old = os.environ.pop("PT_GRID_OCC", None)
+        if mode is not None:
+            os.environ["PT_GRID_OCC"] = mode
+        try:
+            t = Tracer(0)
+        finally:
+            os.environ.pop("PT_GRID_OCC", None)
+            if old is not None:
+                os.environ["PT_GRID_OCC"] = old
+        with t:
+            scene.upload(t)
+            t.target_create(scene.width, scene.height)
+            t.set_accel_mode(capi.ACCEL_GRID)
+            for k in range(3):                       # the third dispatch runs after a list rebuild, i.e. after the flag was set
+                t.dispatch(1 + 24 * k, 24, 1)
+            t.finish()
+            images[mode] = t.readback().copy()
+            rays[mode] = t.stats()["rays"]
+            compared, bad_id, bad_t = t.verify_accel(2)
+            assert compared >= scene.width * scene.height and (bad_id, bad_t) == (0, 0)
+    assert n_bit_mismatch(images["1"], images["0"]) == 0 and n_bit_mismatch(images[None], images["0"]) == 0
+    assert rays["0"] == rays["1"] == rays[None]
+
+
 @pytest.mark.parametrize("workload,size", [("cornell", (640, 360)), ("monkeyhead2", (640, 360)), ("suzanne", (480, 270)),
                                            ("torus_distorted", (960, 540))])
 def test_self_check_of_every_structure(workload, size):
