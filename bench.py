@@ -268,13 +268,20 @@ def cpu_baseline(scene, spp_hint, shading, budget_s=25.0):
         return {"value": rays / dt * 1e-6, "unit": "Mrays/s", "cores": threads, "kind": "port",
                 "sample": f"{scene.name} {scene.width}x{scene.height}, pass 1 of the middle {strip} rows, {rays} rays in {dt:.2f} s "
                           f"(oracle/pt_oracle.c, {threads} threads; a whole pass would take {per_pass:.0f} s)"}
-    passes = int(max(1, min(spp_hint, budget_s / max(per_pass, 1e-6))))
-    t0 = time.perf_counter()
-    _, rays = po.render(sc, u, 1, passes, threads=threads)
-    dt = time.perf_counter() - t0
-    return {"value": rays / dt * 1e-6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"{scene.name} {scene.width}x{scene.height}, passes 1..{passes} of the full frame, "
-                      f"{rays} rays in {dt:.2f} s (oracle/pt_oracle.c, {threads} threads)"}
+    # whole-frame passes in chunks until about twelve seconds of CPU work are done (the strip's timing carries the start-up of
+    # the threads and overestimates a pass, so the chunks are sized as they go)
+    target_s, done, rays, spent = min(12.0, budget_s), 0, 0, 0.0
+    chunk = int(max(1, min(spp_hint, 2.0 / max(per_pass, 1e-6))))
+    while done < spp_hint and spent < target_s:
+        chunk = min(chunk, spp_hint - done)
+        t0 = time.perf_counter()
+        _, r = po.render(sc, u, 1 + done, chunk, threads=threads)
+        dt = time.perf_counter() - t0
+        rays, spent, done = rays + r, spent + dt, done + chunk
+        chunk = int(max(1, min(4 * chunk, (target_s - spent) / max(dt / chunk, 1e-6) + 1)))
+    return {"value": rays / spent * 1e-6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"{scene.name} {scene.width}x{scene.height}, passes 1..{done} of the full frame, "
+                      f"{rays} rays in {spent:.2f} s (oracle/pt_oracle.c, {threads} threads)"}
 
 
 def trace(msg):
