@@ -1043,8 +1043,9 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
 // several-fold in length, and in pt_render_kernel<5, true> every lane waits for the longest walk of its wave before any of
 // them is shaded (measured: 15 % of the lanes active over the kernel). Here a lane is a small state machine and the wave's
 // loop only asks "what does each lane need next":
-//   WALK   one round of its own hierarchy walk: a few node steps, then the leaf it arrived at (same records, same slab
-//          arithmetic, same exact triangle test with the lowest-index rule as intersect_bvh_lanes, so the same hit);
+//   WALK   one round of its own hierarchy walk: a few node steps over the four-child form of the hierarchy, then the leaf it
+//          arrived at (the shader's triangle test with the lowest-index rule for equal distances, and boxes that only ever skip
+//          what that test could not accept: the same hit as every other search mode);
 //   SHADE  its walk is over (or its sample starts from the reused camera-ray hit): it waits until PT_SHADE_BATCH lanes are
 //          waiting, or nobody walks any more, and then the wave runs Shade(), the end of the sample (fs:408-415) and the
 //          start of the next query for all of them at once;
@@ -1055,8 +1056,8 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
 #ifndef PT_SHADE_BATCH
 #define PT_SHADE_BATCH 16
 #endif
-// node steps per round before the lane looks at its leaf (measured on three scenes: 2: +5 %, 3: 0, 5: -6 %, 8: -5 %, 16: +3 %,
-// unbounded: +12 % of the time at 3)
+// node steps per round before the lane looks at its leaf (four-child nodes, 1M triangles / 3,936 / 968: 2 steps 11.9 / 5.74 /
+// 3.63 ms, 3: 11.8 / 5.74 / 3.71, 8: 13.2 / 6.90 / 4.13)
 #ifndef PT_WALK_NODE_STEPS
 #define PT_WALK_NODE_STEPS 3
 #endif

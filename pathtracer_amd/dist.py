@@ -118,7 +118,7 @@ class TileGather:
     `overlapped=False`, or over a backend that cannot gather device memory (gloo rehearsals on a GPU stage through the
     host), `submit` completes the exchange itself. Call both under the stream the renderer uses."""
 
-    def __init__(self, like, rank, world, block=16, group=None, overlapped=True):
+    def __init__(self, like, rank, world, block=16, group=None, overlapped=True, force_exchange=False):
         H = like.shape[0]
         rows = [torch.tensor([y for y0, h in row_blocks(r, world, H, block) for y in range(y0, y0 + h)], dtype=torch.long) for r in range(world)]
         self.max_rows = max(1, max(len(r) for r in rows))
@@ -134,7 +134,9 @@ class TileGather:
         self.world = world
         self.work = None
         self.pending = False
-        on = dist.is_available() and dist.is_initialized() and world > 1
+        # (force_exchange: a one-rank group still goes through the backend's all-gather, for tests of the call sequence)
+        on = dist.is_available() and dist.is_initialized() and (world > 1 or force_exchange)
+        self.force_exchange = bool(force_exchange)
         self.direct = on and (not like.is_cuda or dist.get_backend(group) == "nccl")
         self.staged = on and not self.direct
         self.asynchronous = bool(overlapped and self.direct)
@@ -145,7 +147,7 @@ class TileGather:
         if self.n_mine:
             torch.index_select(image, 0, self.my_rows, out=self.send[:self.n_mine])
         self.pending = True
-        if self.world <= 1 or not (self.direct or self.staged):
+        if (self.world <= 1 and not self.force_exchange) or not (self.direct or self.staged):
             self.recv[:self.max_rows].copy_(self.send)
         elif self.staged:
             host_send, host_recv = self.send.cpu(), torch.empty(self.recv.shape, dtype=self.recv.dtype)

@@ -1,6 +1,6 @@
 """The multi-GPU step over the real backend, as far as one GPU goes: a one-rank "nccl" (RCCL) process group, the render
-into a torch tensor on a side stream, the in-place all-reduce, and the overlapped merge bench.py uses for --gpus N
-(pathtracer_amd.dist.OverlappedSampleMerge), every frame checked. World sizes above 1 are covered on CPU tensors in
+into a torch tensor on a side stream, the in-place all-reduce, the overlapped merge bench.py uses for --gpus N
+(pathtracer_amd.dist.OverlappedSampleMerge) and the tile partition's all-gather (TileGather), every frame checked. World sizes above 1 are covered on CPU tensors in
 test_dist_gloo.py; RCCL refuses two ranks on one device."""
 import os
 import socket
@@ -23,3 +23,4 @@ def test_one_rank_rccl_step_and_overlapped_merge():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "5 steps of render + RCCL all-reduce" in r.stdout
     assert "6 frames with the exchange overlapped" in r.stdout
+    assert "5 frames through the RCCL all-gather of the owned rows" in r.stdout

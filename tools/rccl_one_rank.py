@@ -68,6 +68,30 @@ def main():
     want[..., 3] = 1.0
     assert torch.equal(last, want), "overlapped merge of the last frame differs"
     print(f"ok: 6 frames with the exchange overlapped in {time.perf_counter() - t1:.3f} s")
+    # the tile partition's merge (bench.py --partition tile): all-gather of the owned rows, also beside the next frame
+    t.set_accum_mode(capi.ACCUM_MEAN)
+    gather = ptdist.TileGather(image, 0, 1, 16, overlapped=True, force_exchange=True)
+    assert gather.asynchronous
+    frames = []
+    t2 = time.perf_counter()
+    for step in range(5):
+        with torch.cuda.stream(stream):
+            image.zero_()
+            image[..., 3] = 1.0
+            t.dispatch(1, 8 + step, 1)           # another sample count every frame, so frames differ
+            frames.append(image.clone())
+            if step > 0:
+                got = gather.finish().clone()
+                stream.synchronize()
+                assert torch.equal(got, frames[step - 1]), f"gathered frame {step - 1} differs"
+            gather.submit(image)
+    with torch.cuda.stream(stream):
+        last = gather.finish()
+    stream.synchronize()
+    torch.cuda.synchronize(device)
+    dist.barrier()
+    assert torch.equal(last, frames[-1]), "gathered last frame differs"
+    print(f"ok: 5 frames through the RCCL all-gather of the owned rows in {time.perf_counter() - t2:.3f} s")
     t.close()
     dist.destroy_process_group()
 
