@@ -538,9 +538,9 @@ def main():
     rays, samples, traced = float(counts[0].item()), float(counts[1].item()), float(counts[2].item())
 
     # second half of the headline metric (the ~1M-triangle scene) and the shading the north star names (diffuse/emissive
-    # materials): short runs on rank 0, outside the timed region
+    # materials): short runs of the single-GPU line, outside the timed region (a multi-GPU run reports its own workload only)
     large = materials = materials_large = None
-    if rank == 0 and not args.no_second_scene:
+    if rank == 0 and world == 1 and not args.no_second_scene:
         if args.workload != "instanced":
             large = side_run(local_rank, "instanced", "reference", 256, 8)
         if args.shading != "materials":
@@ -607,7 +607,7 @@ def main():
             out["llvmpipe_recorded"] = {"Mrays_per_s": lp["Mrays_per_s"], "ms_per_pass_median": lp["pass_ms_median"], "cores": lp["threads"],
                                         "renderer": lp["renderer"], "note": "reference pathtracing.fs, passes 1..256 of this workload, timed around glDrawArrays..glFinish "
                                         "in the build container, not on this machine; its final image is bit-identical to this run's (tests/golden/c2_cornell_1080p.json)"}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # (the CPU figure belongs to the single-GPU line; the other ranks would only wait for it)
             out["cpu_baseline"] = cpu_baseline(scene, spp, args.shading)
         print(json.dumps(out), flush=True)
 
