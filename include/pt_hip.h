@@ -69,7 +69,8 @@ typedef enum PtAccelMode {
                            all start at the camera), the LBVH above 128 triangles for PT_SHADE_MATERIALS. Without
                            pt_build_accel, or when fewer triangles are traced than uploaded: the plain loop */
     PT_ACCEL_BRUTE = 1, /* the shader's own loop over all triangles in index order, pathtracing.fs:129 */
-    PT_ACCEL_BVH = 2,   /* require the LBVH: pt_dispatch fails with PT_ERR_STATE when none is built */
+    PT_ACCEL_BVH = 2,   /* require the LBVH: pt_dispatch fails with PT_ERR_STATE when pt_build_accel has not run (for a mesh of at
+                           most 4 triangles pt_build_accel keeps no hierarchy: it would be one leaf, and the loop is its walk) */
     PT_ACCEL_GRID = 4,  /* require the direction grid (built by pt_build_accel, rebuilt when the camera position changes): the
                            shader never moves its ray origin, so every query is "what does the camera position see in this
                            direction"; directions are binned into cube-map cells that list the triangles they can hit.

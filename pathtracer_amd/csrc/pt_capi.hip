@@ -114,6 +114,7 @@ struct PtContext {
     // LBVH (optional)
     PtBvhBuild bvh{};
     bool bvh_built = false;
+    bool bvh_trivial = false;        // pt_build_accel ran on a mesh small enough to be one leaf (no hierarchy kept)
     int32_t bvh_refit_passes = 0;
     PtAccelMode accel_mode = PT_ACCEL_AUTO;
     // direction grid (optional, rebuilt with the records when the camera position changes)
@@ -266,6 +267,7 @@ void free_bvh(PtContext* ctx) {
         if (q) (void)hipFree(q);
     b = PtBvhBuild{};
     ctx->bvh_built = false;
+    ctx->bvh_trivial = false;
 }
 
 void free_grid(PtContext* ctx) {
@@ -500,14 +502,17 @@ PtStatus fill_params(PtContext* ctx, PtKernelParams* p, const Program** prog_out
         }
         p->vnormals = ctx->d_vnormals;
         p->gnormals = ctx->d_gnormals;
-        PT_REQUIRE(ctx->accel_mode != PT_ACCEL_BVH || ctx->bvh_built, PT_ERR_STATE, "PT_ACCEL_BVH but no BVH: call pt_build_accel first");
+        // (a mesh of up to PT_BVH_LEAF_MAX triangles is a single leaf: pt_build_accel keeps no hierarchy and the loop IS its walk)
+        PT_REQUIRE(ctx->accel_mode != PT_ACCEL_BVH || ctx->bvh_built || ctx->bvh_trivial, PT_ERR_STATE,
+                   "PT_ACCEL_BVH but no BVH: call pt_build_accel first");
         // the hierarchy covers the whole mesh, so it serves only when every uploaded triangle is traced
         // and in AUTO mode only when the mesh is big enough for the walk to beat the plain loop
         const bool use_bvh = ctx->bvh_built && ctx->accel_mode != PT_ACCEL_BRUTE && ctx->accel_mode != PT_ACCEL_CULL &&
                              u.num_triangles == ctx->num_triangles &&
                              (ctx->accel_mode == PT_ACCEL_BVH ||
                               u.num_triangles > (is_materials(ctx->shading_mode) ? PT_BVH_AUTO_MIN_TRIANGLES_MOVING : PT_BVH_AUTO_MIN_TRIANGLES));
-        PT_REQUIRE(use_bvh || ctx->accel_mode != PT_ACCEL_BVH, PT_ERR_STATE, "the BVH covers all %d triangles but u_NumTriangles = %d",
+        PT_REQUIRE(use_bvh || ctx->accel_mode != PT_ACCEL_BVH || (ctx->bvh_trivial && u.num_triangles == ctx->num_triangles), PT_ERR_STATE,
+                   "the BVH covers all %d triangles but u_NumTriangles = %d",
                    ctx->num_triangles, u.num_triangles);
         p->shading_mode = (int32_t)ctx->shading_mode;
         const bool grid_possible = ctx->grid_wanted && ctx->shading_mode == PT_SHADE_REFERENCE && u.num_triangles == ctx->num_triangles &&
@@ -852,7 +857,10 @@ PtStatus pt_build_accel(PtContext* ctx) {
     ctx->grid_wanted = true;
     ctx->records_valid = false;
     const int32_t n = ctx->num_triangles;
-    if (n <= PT_BVH_LEAF_MAX) return PT_OK;  // a single leaf: the plain loop is the traversal
+    if (n <= PT_BVH_LEAF_MAX) {  // a single leaf: the plain loop is the traversal
+        ctx->bvh_trivial = true;
+        return PT_OK;
+    }
     PtBvhBuild& b = ctx->bvh;
     b.num_triangles = n;
     b.vertices = ctx->d_vertices;

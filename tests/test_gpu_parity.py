@@ -180,12 +180,12 @@ def _awkward_meshes():
     out["spread"] = np.concatenate([cluster, far, big]).astype(np.float32)
     one = np.array([[[-1, -1, 6.0], [0, 1, 6.0], [1, -1, 6.0]]], np.float32)
     out["same"] = np.repeat(one, 37, axis=0)
-    for n in (5, 6, 9):
+    for n in (3, 5, 9):
         out[f"few{n}"] = (rng.uniform(-1.5, 1.5, (n, 1, 3)) + np.array([0, 0, 6.0]) + rng.uniform(-1.0, 1.0, (n, 3, 3))).astype(np.float32)
     return out
 
 
-@pytest.mark.parametrize("layout", ["flat", "spread", "same", "few5", "few6", "few9"])
+@pytest.mark.parametrize("layout", ["flat", "spread", "same", "few3", "few5", "few9"])
 def test_materials_walk_on_awkward_layouts(tracer, layout):
     """The decoupled walk over the four-child form against the loop over all triangles, image and ray count bit for bit, and the
     device-side self-check of the form, on layouts chosen against its box encoding."""
@@ -220,8 +220,9 @@ def test_materials_walk_on_awkward_layouts(tracer, layout):
         rays[accel] = tracer.stats()["rays"]
     assert n_bit_mismatch(images["bvh"], images["brute"]) == 0
     assert rays["bvh"] == rays["brute"] > W * H * 4
-    compared, bad_id, bad_t = tracer.verify_accel(3)
-    assert compared >= W * H and bad_id == 0 and bad_t == 0
+    if nt > 4:   # (up to four triangles are one leaf: pt_build_accel keeps no hierarchy and PT_ACCEL_BVH runs the loop)
+        compared, bad_id, bad_t = tracer.verify_accel(3)
+        assert compared >= W * H and bad_id == 0 and bad_t == 0
     tracer.set_accel_mode(capi.ACCEL_AUTO)
     tracer.set_shading_mode(0)
     tracer.program_destroy(prog)
