@@ -20,6 +20,8 @@ VARIANTS = {
     "nosky": ["-DPT_V_NO_SKY"],
     "maxilp": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
     "memclause": ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"],
+    "nounroll": ["-fno-unroll-loops"],
+    "o2": ["-O2"],
 }
 
 
