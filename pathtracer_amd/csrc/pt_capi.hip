@@ -156,6 +156,8 @@ struct PtContext {
     int lane_walk = 1;                    // materials mode: 1 = one hierarchy walk per lane, lanes decoupled; PT_LANE_WALK=2: per lane, all
                                           // lanes of a wave in step; PT_LANE_WALK=0: one walk per wave
     bool auto_grid = true;                // PT_AUTO_GRID=0: PT_ACCEL_AUTO never picks the direction grid (for comparisons)
+    bool camera_ray_grid = true;          // PT_CAMERA_RAY_GRID=0: the materials mode walks the hierarchy for its camera rays too
+    uint32_t dispatches_here = 0;         // dispatches finished since the mesh or the camera position last changed
     bool keep_unreachable = false;        // PT_KEEP_UNREACHABLE=1: the loop walks all records (to measure the compaction)
     int32_t sched_win[4] = {-1, -1, -1, -1};  // window the costs were measured for
     bool sched_have_cost = false;
@@ -415,6 +417,7 @@ PtStatus ensure_records(PtContext* ctx) {
     ctx->primary_cache_valid = false;
     ctx->list_valid = false;  // new mesh or camera position: the tile costs will change
     ctx->costs_stale = true;
+    ctx->dispatches_here = 0;
     return PT_OK;
 }
 
@@ -528,13 +531,29 @@ PtStatus fill_params(PtContext* ctx, PtKernelParams* p, const Program** prog_out
             PtStatus bs = ensure_bvh_emit(ctx);
             if (bs != PT_OK) return bs;
         }
-        if (use_grid) {
+        // The materials mode walks the hierarchy (its bounce rays start anywhere), but the camera rays of a view all start at the
+        // camera: with the search left to the library their hits come from the direction grid. Measured per dispatch of the
+        // 4K frame of 1M triangles: 0.37 ms less (1 sample: 1.74 -> 1.37 ms; 16: 10.4 -> 10.2), 968 triangles at 1080p,
+        // 16 samples: 1.44 -> 1.27 ms. Building the grid of the million triangles takes 0.9 ms per camera position, so it
+        // starts with the second dispatch from a position: a camera that moves every frame never pays for it. A call that
+        // may not allocate uses the grid only if an earlier dispatch of this camera position built it.
+        bool grid_for_camera_rays = false;
+        if (is_materials(ctx->shading_mode) && use_bvh && ctx->lane_walk == 1 && ctx->primary_reuse && ctx->grid_wanted && ctx->auto_grid &&
+            ctx->accel_mode == PT_ACCEL_AUTO && ctx->camera_ray_grid && u.depth > 0 && (ctx->grid_valid || (ctx->dispatches_here >= 1 && !ctx->no_alloc))) {
+            PtStatus gs = ensure_grid(ctx);
+            if (gs != PT_OK) return gs;
+            grid_for_camera_rays = ctx->grid_built;
+        }
+        if (use_grid || grid_for_camera_rays) {
             p->grid_cells = ctx->grid.cells;
             p->grid_list = ctx->grid.list;
             p->grid_occ = ctx->grid_use_occ ? ctx->grid.occ : nullptr;
             p->grid_occ_flag = ctx->d_grid_occ_flag;
             p->grid_tris = ctx->d_tris_grid;
             p->grid_res = ctx->grid.res;
+        }
+        if (use_grid) {
+            // (the grid answers every query of the dispatch: nothing else to attach)
         } else if (is_materials(ctx->shading_mode)) {
             PT_REQUIRE(ctx->accel_mode != PT_ACCEL_CULL, PT_ERR_STATE, "PT_ACCEL_CULL serves rays from the camera only; PT_SHADE_MATERIALS moves the origin");
             PT_REQUIRE(ctx->d_materials != nullptr, PT_ERR_STATE, "PT_SHADE_MATERIALS but no material table: call pt_upload_materials first");
@@ -658,6 +677,7 @@ PtStatus pt_create(int32_t device, PtContext** out_ctx) {
 
     if (const char* g = getenv("PT_SCHED_SORT")) ctx->sched_sort = atoi(g);
     if (const char* g = getenv("PT_AUTO_GRID")) ctx->auto_grid = g[0] != '0';
+    if (const char* g = getenv("PT_CAMERA_RAY_GRID")) ctx->camera_ray_grid = g[0] != '0';
     if (const char* g = getenv("PT_PRIMARY_CACHE")) ctx->primary_cache_enabled = g[0] != '0';
     if (const char* g = getenv("PT_GRID_OCC")) ctx->grid_occ_override = atoi(g) != 0;
     if (const char* g = getenv("PT_GRID_QUEUE")) ctx->grid_queue_override = atoi(g);
@@ -1250,6 +1270,7 @@ PtStatus pt_dispatch(PtContext* ctx, int32_t first_sample, int32_t num_samples, 
         ctx->ev_pending = true;
     }
     ctx->dispatches += 1;
+    ctx->dispatches_here += 1;
     return PT_OK;
 }
 
@@ -1333,6 +1354,7 @@ PtStatus pt_dispatch_static(PtContext* ctx, int32_t first_sample, int32_t num_sa
         ctx->ev_pending = true;
     }
     ctx->dispatches += 1;
+    ctx->dispatches_here += 1;
     return PT_OK;
 }
 

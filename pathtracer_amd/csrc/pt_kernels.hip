@@ -1306,6 +1306,17 @@ __global__ __launch_bounds__(64, PT_DECOUPLED_MIN_WAVES) void pt_render_decouple
         state = SHADE;
     };
 
+    // All camera rays share their origin, so where the direction grid of this camera position is at hand the camera ray's
+    // hit comes from it instead of a walk: the same exact test and lowest-index rule, a cell and a record or two to fetch.
+    if (reuse && p.grid_cells) {
+        if (state == WALK) {
+            unsigned grid_tests = 0;
+            v3 gn;
+            w.h = intersect_grid(p, rd, grid_tests, gn, p.grid_occ != nullptr);
+            walk_over();
+        }
+    }
+
     PT_PHASE_D(tk_hand)
     for (;;) {
         const unsigned long long walking = __builtin_amdgcn_ballot_w64(state == WALK);

@@ -413,6 +413,75 @@ def test_block_bits_of_the_direction_grid_change_nothing(workload, size):
     assert rays["0"] == rays["1"] == rays[None]
 
 
+@pytest.mark.parametrize("workload,size,spp", [("monkeyhead2", (480, 270), 6), ("suzanne", (640, 360), 5), ("instanced", (960, 540), 3),
+                                               ("torus_distorted", (480, 270), 6)])
+def test_materials_mode_camera_rays_through_the_direction_grid(workload, size, spp):
+    """With the search left to the library (PT_ACCEL_AUTO) the materials mode takes the camera rays' hits from the direction grid,
+    from the second dispatch of a camera position on, and walks the hierarchy for the bounce rays only. Against the hierarchy for
+    every ray (PT_ACCEL_BVH, and PT_CAMERA_RAY_GRID=0): the same image and ray count bit for bit, in one dispatch, in single-sample
+    frames, in a window, and after a camera move; the camera rays' ids and distances are the same too."""
+    import os
+    from pathtracer_amd import Tracer, capi
+    from pathtracer_amd.scenes import SceneData
+    scene = SceneData(workload, *size)
+    W, H = scene.width, scene.height
+
+    def run(t, accel):
+        out = {}
+        scene.upload(t, shading="materials")
+        t.target_create(W, H)
+        t.set_accel_mode(accel)
+        t.reset_stats()
+        t.dispatch(1, spp, 1)
+        for k in range(3):                                     # frames of one sample each
+            t.dispatch(spp + 1 + k, 1, 1)
+        t.finish()
+        out["full"] = t.readback().copy()
+        out["rays"] = t.stats()["rays"]
+        out["ids"], out["t"] = t.readback_primary()
+        t.set_window(W // 5, H // 4, W // 2, H // 3)
+        t.target_clear()
+        t.dispatch(1, spp, 1)
+        t.finish()
+        out["window"] = t.readback().copy()
+        t.set_window(0, 0, W, H)
+        cam = scene.camera.copy()                               # the camera a little to the side: records and grid are redone
+        shift = np.float32(0.03) * np.abs(cam[6:9]).max() * np.array([1.0, 0.5, 0.0], np.float32)
+        cam[0:3] += shift
+        cam[3:6] += shift
+        t.set_uniforms(cam, scene.num_triangles, 10)
+        t.target_clear()
+        t.dispatch(1, 2, 1)                                      # (first dispatch from the new position: no grid yet)
+        t.dispatch(3, spp, 1)
+        t.finish()
+        out["moved"] = t.readback().copy()
+        out["grid_entries"] = t.stats()["grid_entries"]
+        return out
+
+    results = {}
+    for label, accel, env in (("grid", capi.ACCEL_AUTO, None), ("walk", capi.ACCEL_BVH, None), ("auto_walk", capi.ACCEL_AUTO, "0")):
+        old = os.environ.pop("PT_CAMERA_RAY_GRID", None)
+        if env is not None:
+            os.environ["PT_CAMERA_RAY_GRID"] = env
+        try:
+            t = Tracer(0)
+        finally:
+            os.environ.pop("PT_CAMERA_RAY_GRID", None)
+            if old is not None:
+                os.environ["PT_CAMERA_RAY_GRID"] = old
+        with t:
+            results[label] = run(t, accel)
+    g = results["grid"]
+    for other in ("walk", "auto_walk"):
+        o = results[other]
+        assert n_bit_mismatch(g["full"], o["full"]) == 0 and n_bit_mismatch(g["window"], o["window"]) == 0
+        assert n_bit_mismatch(g["moved"], o["moved"]) == 0 and n_bit_mismatch(g["moved"], g["full"]) > 0
+        assert g["rays"] == o["rays"]
+        assert np.array_equal(g["ids"], o["ids"]) and np.array_equal(g["t"].view(np.uint32), o["t"].view(np.uint32))
+    assert g["rays"] > W * H * (spp + 3)
+    assert g["grid_entries"] > 0 and results["walk"]["grid_entries"] == 0 and results["auto_walk"]["grid_entries"] == 0
+
+
 @pytest.mark.parametrize("workload,size", [("cornell", (640, 360)), ("monkeyhead2", (640, 360)), ("suzanne", (480, 270)),
                                            ("torus_distorted", (960, 540))])
 def test_self_check_of_every_structure(workload, size):
