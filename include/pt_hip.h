@@ -196,10 +196,19 @@ PtStatus pt_set_shading_mode(PtContext* ctx, PtShadingMode mode);
  * does. The image is identical either way; PtStats::rays counts the query for every sample in both cases,
  * PtStats::rays_traced only the evaluations. No effect on dispatches of a single sample. */
 PtStatus pt_set_primary_reuse(PtContext* ctx, int32_t enable);
-/* Builds a linear BVH over the uploaded mesh on the device (Morton codes, radix sort, Karras hierarchy, bottom-up
- * boxes). No counterpart in the reference, whose shader tests every triangle for every ray; needed for scenes beyond a
- * few thousand triangles. A new pt_upload_mesh discards it. Meshes of at most 4 triangles need none (PT_OK, no-op). */
+/* Builds a bounding volume hierarchy over the uploaded mesh (and makes the direction grid available, see PT_ACCEL_GRID). No
+ * counterpart in the reference, whose shader tests every triangle for every ray; needed for scenes beyond a few thousand
+ * triangles. A new pt_upload_mesh discards it. Meshes of at most 4 triangles need none (PT_OK, no-op). Synchronises. */
 PtStatus pt_build_accel(PtContext* ctx);
+/* Which builder the next pt_build_accel uses. Images do not depend on it (the walk only ever skips triangles the exact test
+ * could not accept); the time of the walks and of the build does. */
+typedef enum PtBvhBuilder {
+    PT_BVH_BUILDER_SAH = 0,    /* default: top-down on the host, splits by the binned surface-area heuristic, up to 16 threads;
+                                  0.1 s for a million triangles; its walks fetch 10-20 % fewer records */
+    PT_BVH_BUILDER_MORTON = 1  /* on the device: Morton codes, radix sort, Karras hierarchy; 11 ms for a million triangles --
+                                  for meshes that are rebuilt often */
+} PtBvhBuilder;
+PtStatus pt_set_bvh_builder(PtContext* ctx, PtBvhBuilder builder);
 PtStatus pt_set_accel_mode(PtContext* ctx, PtAccelMode mode);
 
 /* ---- accumulation target: replaces the two RGBA32F textures + FBOs (PathTracer.cpp:1136-1152) ------------ */

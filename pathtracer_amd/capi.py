@@ -18,6 +18,7 @@ NORMALS_VERTEX, NORMALS_GEOMETRIC = 0, 1
 ACCUM_MEAN, ACCUM_SUM = 0, 1
 ACCEL_AUTO, ACCEL_BRUTE, ACCEL_BVH, ACCEL_CULL, ACCEL_GRID = 0, 1, 2, 3, 4
 SHADE_REFERENCE, SHADE_MATERIALS, SHADE_MATERIALS_UNIT = 0, 1, 2
+BVH_BUILDER_SAH, BVH_BUILDER_MORTON = 0, 1
 
 
 class PtUniforms(C.Structure):
@@ -59,6 +60,7 @@ SIGNATURES = {
     "pt_set_shading_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "pt_set_primary_reuse": (C.c_int, [C.c_void_p, C.c_int32]),
     "pt_build_accel": (C.c_int, [C.c_void_p]),
+    "pt_set_bvh_builder": (C.c_int, [C.c_void_p, C.c_int]),
     "pt_set_accel_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "pt_target_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "pt_target_bind_external": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
@@ -179,6 +181,9 @@ class Tracer:
     def upload_material_ids(self, ids):
         a = np.ascontiguousarray(ids, np.int32).reshape(-1)
         check(self._lib.pt_upload_material_ids(self._ctx, a.ctypes.data, len(a)), self._lib)
+
+    def set_bvh_builder(self, builder):
+        check(self._lib.pt_set_bvh_builder(self._ctx, builder), self._lib)
 
     def set_primary_reuse(self, enable):
         check(self._lib.pt_set_primary_reuse(self._ctx, 1 if enable else 0), self._lib)

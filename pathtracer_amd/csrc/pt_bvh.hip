@@ -1,5 +1,6 @@
-// Device-built LBVH over the mesh (Morton codes -> radix sort -> Karras hierarchy -> refit), emitted as 64-byte
-// "two children per record" nodes for wave-coherent traversal. The reference has no acceleration structure (its
+// Bounding volume hierarchy over the mesh -- built on the device (Morton codes -> radix sort -> Karras hierarchy) or, by
+// default, top-down on the host with the surface-area heuristic; boxes bottom-up on the device either way -- emitted as 64-byte
+// "two children per record" nodes for wave-coherent traversal and as four-child nodes with 16-bit boxes for the per-lane walk. The reference has no acceleration structure (its
 // shader loops over every triangle, pathtracing.fs:129); this one exists so that scenes far beyond a few thousand
 // triangles are traceable, and it must not change a single result: traversal (pt_kernels.hip) only ever SKIPS triangles
 // that the exact test could not accept, and resolves equal distances by the lowest triangle index, which is what the
@@ -7,6 +8,12 @@
 #include "pt_internal.h"
 
 #include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <array>
+#include <atomic>
+#include <thread>
+#include <vector>
 
 namespace {
 
@@ -309,28 +316,131 @@ __global__ __launch_bounds__(256) void bvh_gather_qrecords(const uint32_t* __res
 
 inline dim3 grid_for(int n) { return dim3((unsigned)((n + 255) / 256)); }
 
-}  // namespace
+// ---- host-side builder: top-down, binned surface-area heuristic --------------------------------------------------------------
+// Splits a range of triangles where the summed (area x count) of the two sides is smallest among 3 x 15 candidate planes through
+// the centroid bounds; writes the same arrays the Morton-code builder writes (order, child, range; node 0 the root; the subtree
+// over c triangles owns c - 1 consecutive node indices, its left subtree first). Takes far longer than the device build and makes
+// hierarchies whose walks fetch fewer records.
+struct HostBox {
+    float lo[3], hi[3];
+    void reset() { for (int k = 0; k < 3; ++k) { lo[k] = 3.0e38f; hi[k] = -3.0e38f; } }
+    void add(const float* b) { for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], b[k]); hi[k] = std::max(hi[k], b[3 + k]); } }
+    void add(const HostBox& o) { for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], o.lo[k]); hi[k] = std::max(hi[k], o.hi[k]); } }
+    float half_area() const {
+        const float x = hi[0] - lo[0], y = hi[1] - lo[1], z = hi[2] - lo[2];
+        return x < 0.f ? 0.f : (x * y + y * z) + z * x;
+    }
+};
 
-size_t pt_bvh_sort_temp_bytes(int32_t n) {
-    size_t bytes = 0, scan = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
-                                             (const uint32_t*)nullptr, (uint32_t*)nullptr, n, 0, 63, nullptr);
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan, (const int*)nullptr, (int*)nullptr, n, nullptr);  // numbering of the wide nodes
-    return bytes > scan ? bytes : scan;
-}
+struct SahBuilder {
+    static constexpr int kBins = 16;
+    const float* tri_box;   // n x 6
+    uint32_t* order;
+    int* child;
+    int* range;
 
-hipError_t pt_bvh_build_topology(const PtBvhBuild& b, hipStream_t stream, int32_t* out_passes) {
+    // where the range [first, last] is cut: the first position of its right part
+    int split(int first, int last) const {
+        const int count = last - first + 1;
+        float clo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, chi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+        for (int p = first; p <= last; ++p) {
+            const float* b = tri_box + 6 * (size_t)order[p];
+            for (int k = 0; k < 3; ++k) {
+                const float c = 0.5f * b[k] + 0.5f * b[3 + k];
+                clo[k] = std::min(clo[k], c);
+                chi[k] = std::max(chi[k], c);
+            }
+        }
+        int best_axis = -1, best_bin = 0;
+        float best_cost = 3.0e38f, scale[3];
+        if (count > 2) {
+            HostBox bins[3][kBins];
+            int counts[3][kBins];
+            for (int k = 0; k < 3; ++k) {
+                scale[k] = chi[k] > clo[k] ? (float)kBins / (chi[k] - clo[k]) : 0.f;
+                for (int j = 0; j < kBins; ++j) { bins[k][j].reset(); counts[k][j] = 0; }
+            }
+            for (int p = first; p <= last; ++p) {
+                const float* b = tri_box + 6 * (size_t)order[p];
+                for (int k = 0; k < 3; ++k) {
+                    const float c = 0.5f * b[k] + 0.5f * b[3 + k];
+                    const int j = std::min(kBins - 1, std::max(0, (int)((c - clo[k]) * scale[k])));
+                    bins[k][j].add(b);
+                    ++counts[k][j];
+                }
+            }
+            for (int k = 0; k < 3; ++k) {
+                if (scale[k] == 0.f) continue;
+                float right_area[kBins];
+                HostBox acc;
+                acc.reset();
+                for (int j = kBins - 1; j > 0; --j) {
+                    if (counts[k][j]) acc.add(bins[k][j]);
+                    right_area[j] = acc.half_area();
+                }
+                acc.reset();
+                int left = 0;
+                for (int j = 0; j + 1 < kBins; ++j) {
+                    if (counts[k][j]) acc.add(bins[k][j]);
+                    left += counts[k][j];
+                    if (left == 0 || left == count) continue;
+                    const float cost = acc.half_area() * (float)left + right_area[j + 1] * (float)(count - left);
+                    if (cost < best_cost) { best_cost = cost; best_axis = k; best_bin = j; }
+                }
+            }
+        }
+        if (best_axis >= 0) {
+            const int k = best_axis;
+            uint32_t* mid = std::partition(order + first, order + last + 1, [&](uint32_t id) {
+                const float* b = tri_box + 6 * (size_t)id;
+                const float c = 0.5f * b[k] + 0.5f * b[3 + k];
+                return std::min(kBins - 1, std::max(0, (int)((c - clo[k]) * scale[k]))) <= best_bin;
+            });
+            const int at = (int)(mid - order);
+            if (at > first && at <= last) return at;
+        }
+        // all centroids in one place (or two triangles): halves, by the widest axis of the centroids where there is one
+        int k = 0;
+        for (int a = 1; a < 3; ++a) if (chi[a] - clo[a] > chi[k] - clo[k]) k = a;
+        const int at = first + count / 2;
+        if (chi[k] > clo[k])
+            std::nth_element(order + first, order + at, order + last + 1, [&](uint32_t x, uint32_t y) {
+                const float* bx = tri_box + 6 * (size_t)x; const float* by = tri_box + 6 * (size_t)y;
+                const float cx = 0.5f * bx[k] + 0.5f * bx[3 + k], cy = 0.5f * by[k] + 0.5f * by[3 + k];
+                return cx < cy || (cx == cy && x < y);
+            });
+        return at;
+    }
+
+    // the subtree over [first, last] (two triangles or more), its root at index `node`
+    void build(int node, int first, int last, std::vector<std::array<int, 3>>* defer, int defer_below) {
+        struct Item { int node, first, last; };
+        std::vector<Item> stack;
+        stack.push_back({node, first, last});
+        while (!stack.empty()) {
+            const Item it = stack.back();
+            stack.pop_back();
+            if (defer && it.last - it.first + 1 <= defer_below) {   // left to a worker thread
+                defer->push_back({it.node, it.first, it.last});
+                continue;
+            }
+            const int at = split(it.first, it.last);
+            const int left_count = at - it.first, right_count = it.last - at + 1;
+            range[2 * it.node] = it.first;
+            range[2 * it.node + 1] = it.last;
+            const int left_node = it.node + 1, right_node = it.node + left_count;   // (a subtree over c triangles has c - 1 nodes)
+            child[2 * it.node] = left_count == 1 ? ~it.first : left_node;
+            child[2 * it.node + 1] = right_count == 1 ? ~at : right_node;
+            if (left_count > 1) stack.push_back({left_node, it.first, at - 1});
+            if (right_count > 1) stack.push_back({right_node, at, it.last});
+        }
+    }
+};
+
+// Boxes bottom-up and the numbering of the wide nodes, for whatever made order / child / range (node 0 is the root).
+hipError_t finish_topology(const PtBvhBuild& b, hipStream_t stream, int32_t* out_passes) {
     const int n = b.num_triangles;
-    if (out_passes) *out_passes = 0;
-    if (n < 2) return hipSuccess;
-    hipLaunchKernelGGL(bvh_init_scene_box, dim3(1), dim3(64), 0, stream, b.scene_box);
-    hipLaunchKernelGGL(bvh_tri_boxes, grid_for(n), dim3(256), 0, stream, b.vertices, b.indices, n, b.tri_box, b.scene_box);
-    hipLaunchKernelGGL(bvh_morton_keys, grid_for(n), dim3(256), 0, stream, b.tri_box, b.scene_box, n, b.keys_tmp, b.order_tmp);
-    size_t bytes = b.sort_tmp_bytes;
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(b.sort_tmp, bytes, b.keys_tmp, b.keys, b.order_tmp, b.order, n, 0, 63, stream);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(bvh_hierarchy, grid_for(n - 1), dim3(256), 0, stream, b.keys, n, b.child, b.range);
-    e = hipMemsetAsync(b.done, 0, (size_t)(n - 1) * sizeof(int), stream);
+    hipError_t e = hipMemsetAsync(b.done, 0, (size_t)(n - 1) * sizeof(int), stream);
     if (e != hipSuccess) return e;
     int remaining = n - 1;
     e = hipMemcpyAsync(b.remaining, &remaining, sizeof(int), hipMemcpyHostToDevice, stream);
@@ -351,11 +461,96 @@ hipError_t pt_bvh_build_topology(const PtBvhBuild& b, hipStream_t stream, int32_
     // numbering of the wide nodes (every second level)
     hipLaunchKernelGGL(bvh_parents, grid_for(n - 1), dim3(256), 0, stream, b.child, n, b.parent);
     hipLaunchKernelGGL(bvh_wide_flags, grid_for(n - 1), dim3(256), 0, stream, b.parent, b.range, n, b.wide_flag);
-    bytes = b.sort_tmp_bytes;
+    size_t bytes = b.sort_tmp_bytes;
     e = hipcub::DeviceScan::ExclusiveSum(b.sort_tmp, bytes, b.wide_flag, b.wide_index, n - 1, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(bvh_wide_indices, grid_for(n - 1), dim3(256), 0, stream, b.wide_flag, n, b.wide_index);
     return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t pt_bvh_build_topology_sah(const PtBvhBuild& b, hipStream_t stream, int32_t* out_passes) {
+    const int n = b.num_triangles;
+    if (out_passes) *out_passes = 0;
+    if (n < 2) return hipSuccess;
+    hipLaunchKernelGGL(bvh_init_scene_box, dim3(1), dim3(64), 0, stream, b.scene_box);
+    hipLaunchKernelGGL(bvh_tri_boxes, grid_for(n), dim3(256), 0, stream, b.vertices, b.indices, n, b.tri_box, b.scene_box);
+    std::vector<float> tri_box;
+    std::vector<uint32_t> order;
+    std::vector<int> child, range;
+    try {
+        tri_box.resize((size_t)n * 6);
+        order.resize((size_t)n);
+        child.resize((size_t)(n - 1) * 2);
+        range.resize((size_t)(n - 1) * 2);
+    } catch (const std::bad_alloc&) {
+        return hipErrorOutOfMemory;
+    }
+    hipError_t e = hipMemcpyAsync(tri_box.data(), b.tri_box, tri_box.size() * sizeof(float), hipMemcpyDeviceToHost, stream);
+    if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return e;
+    for (int i = 0; i < n; ++i) order[(size_t)i] = (uint32_t)i;
+    SahBuilder sb{tri_box.data(), order.data(), child.data(), range.data()};
+    // The top of the tree on this thread, down to subtrees of at most n / 64 triangles; those are shared out among this thread and
+    // up to 15 more (they work on disjoint parts of every array, and a subtree's node indices follow from its position, so the
+    // result does not depend on which thread built what). Threads that cannot be started are done without.
+    std::vector<std::array<int, 3>> parts;
+    std::atomic<size_t> next{0};
+    std::atomic<bool> failed{false};
+    auto work = [&]() {
+        try {
+            for (size_t k = next.fetch_add(1); k < parts.size(); k = next.fetch_add(1)) sb.build(parts[k][0], parts[k][1], parts[k][2], nullptr, 0);
+        } catch (const std::exception&) {
+            failed = true;
+        }
+    };
+    std::vector<std::thread> pool;
+    try {
+        const int threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+        sb.build(0, 0, n - 1, threads > 1 && n >= 4096 ? &parts : nullptr, std::max(2, n / 64));
+        if (!parts.empty()) {
+            pool.reserve((size_t)threads);
+            try {
+                for (int t = 1; t < threads; ++t) pool.emplace_back(work);
+            } catch (const std::exception&) {
+            }
+        }
+    } catch (const std::exception&) {
+        failed = true;
+    }
+    if (!failed) work();
+    for (auto& th : pool) th.join();
+    if (failed) return hipErrorOutOfMemory;
+    e = hipMemcpyAsync(b.order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(b.child, child.data(), child.size() * sizeof(int), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(b.range, range.data(), range.size() * sizeof(int), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);   // the host arrays go out of scope
+    if (e != hipSuccess) return e;
+    return finish_topology(b, stream, out_passes);
+}
+
+size_t pt_bvh_sort_temp_bytes(int32_t n) {
+    size_t bytes = 0, scan = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                                             (const uint32_t*)nullptr, (uint32_t*)nullptr, n, 0, 63, nullptr);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan, (const int*)nullptr, (int*)nullptr, n, nullptr);  // numbering of the wide nodes
+    return bytes > scan ? bytes : scan;
+}
+
+hipError_t pt_bvh_build_topology(const PtBvhBuild& b, hipStream_t stream, int32_t* out_passes) {
+    const int n = b.num_triangles;
+    if (out_passes) *out_passes = 0;
+    if (n < 2) return hipSuccess;
+    hipLaunchKernelGGL(bvh_init_scene_box, dim3(1), dim3(64), 0, stream, b.scene_box);
+    hipLaunchKernelGGL(bvh_tri_boxes, grid_for(n), dim3(256), 0, stream, b.vertices, b.indices, n, b.tri_box, b.scene_box);
+    hipLaunchKernelGGL(bvh_morton_keys, grid_for(n), dim3(256), 0, stream, b.tri_box, b.scene_box, n, b.keys_tmp, b.order_tmp);
+    size_t bytes = b.sort_tmp_bytes;
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(b.sort_tmp, bytes, b.keys_tmp, b.keys, b.order_tmp, b.order, n, 0, 63, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(bvh_hierarchy, grid_for(n - 1), dim3(256), 0, stream, b.keys, n, b.child, b.range);
+    return finish_topology(b, stream, out_passes);
 }
 
 hipError_t pt_bvh_emit(const PtBvhBuild& b, const float ro[3], const float* tris, const float* tris_abs, hipStream_t stream) {

@@ -117,6 +117,7 @@ struct PtContext {
     bool bvh_trivial = false;        // pt_build_accel ran on a mesh small enough to be one leaf (no hierarchy kept)
     int32_t bvh_refit_passes = 0;
     PtAccelMode accel_mode = PT_ACCEL_AUTO;
+    PtBvhBuilder bvh_builder = PT_BVH_BUILDER_SAH;   // PT_BVH_BUILDER=morton / sah sets a context's initial choice
     // direction grid (optional, rebuilt with the records when the camera position changes)
     PtGridBuild grid{};
     bool grid_wanted = false;   // pt_build_accel was called for this mesh
@@ -677,6 +678,7 @@ PtStatus pt_create(int32_t device, PtContext** out_ctx) {
 
     if (const char* g = getenv("PT_SCHED_SORT")) ctx->sched_sort = atoi(g);
     if (const char* g = getenv("PT_AUTO_GRID")) ctx->auto_grid = g[0] != '0';
+    if (const char* g = getenv("PT_BVH_BUILDER")) ctx->bvh_builder = g[0] == 'm' ? PT_BVH_BUILDER_MORTON : PT_BVH_BUILDER_SAH;
     if (const char* g = getenv("PT_CAMERA_RAY_GRID")) ctx->camera_ray_grid = g[0] != '0';
     if (const char* g = getenv("PT_PRIMARY_CACHE")) ctx->primary_cache_enabled = g[0] != '0';
     if (const char* g = getenv("PT_GRID_OCC")) ctx->grid_occ_override = atoi(g) != 0;
@@ -914,7 +916,9 @@ PtStatus pt_build_accel(PtContext* ctx) {
     alloc(&b.wide_flag, ni * sizeof(int));
     alloc(&b.tris_q, (nn + PT_TRI_PAD) * PT_BVH_QTRI_FLOATS * sizeof(float));
     alloc(&b.qframe, 8 * sizeof(float));
-    if (e == hipSuccess) e = pt_bvh_build_topology(b, ctx->stream, &ctx->bvh_refit_passes);
+    if (e == hipSuccess)
+        e = ctx->bvh_builder == PT_BVH_BUILDER_SAH ? pt_bvh_build_topology_sah(b, ctx->stream, &ctx->bvh_refit_passes)
+                                                   : pt_bvh_build_topology(b, ctx->stream, &ctx->bvh_refit_passes);
     if (e != hipSuccess) {
         free_bvh(ctx);
         return fail(PT_ERR_HIP, "BVH build failed: %s", hipGetErrorString(e));
@@ -922,6 +926,14 @@ PtStatus pt_build_accel(PtContext* ctx) {
     if (getenv("PT_DEBUG_SCHED")) fprintf(stderr, "[pt bvh] %d triangles, hierarchy finished after %d bottom-up sweeps\n", n, ctx->bvh_refit_passes);
     ctx->bvh_built = true;
     ctx->records_valid = false;  // leaf-order records and origin-relative boxes are emitted with the next records
+    return PT_OK;
+}
+
+PtStatus pt_set_bvh_builder(PtContext* ctx, PtBvhBuilder builder) {
+    PtStatus s = bind(ctx);
+    if (s != PT_OK) return s;
+    PT_REQUIRE(builder == PT_BVH_BUILDER_SAH || builder == PT_BVH_BUILDER_MORTON, PT_ERR_INVALID_ARGUMENT, "unknown BVH builder %d", (int)builder);
+    ctx->bvh_builder = builder;
     return PT_OK;
 }
 

@@ -1,4 +1,4 @@
-"""The device-built LBVH must not change a single result: closest-hit ids, distances and radiance through the BVH
+"""The hierarchy (either builder's) must not change a single result: closest-hit ids, distances and radiance through the BVH
 equal the all-triangles loop (the shader's own formulation) bit for bit -- including exact ties, which the shader's
 ascending loop with a strict '<' gives to the lowest triangle index."""
 import numpy as np
@@ -42,6 +42,18 @@ def both_modes(t, verts, idx, cam, W, H, normal_mode, spp=3, window=None):
             t.dispatch(1, spp, 1)
             t.finish()
         res[name] = (ids, ts, t.readback(), t.stats()["rays"])
+    # the hierarchy of the other builder (the default is the host's surface-area builder)
+    t.set_bvh_builder(capi.BVH_BUILDER_MORTON)
+    t.build_accel()
+    t.set_bvh_builder(capi.BVH_BUILDER_SAH)
+    t.set_accel_mode(capi.ACCEL_BVH)
+    t.target_clear()
+    t.reset_stats()
+    ids, ts = t.readback_primary()
+    if spp:
+        t.dispatch(1, spp, 1)
+        t.finish()
+    res["bvh_morton"] = (ids, ts, t.readback(), t.stats()["rays"])
     t.set_accel_mode(capi.ACCEL_AUTO)
     t.program_destroy(prog)
     return res
@@ -49,7 +61,7 @@ def both_modes(t, verts, idx, cam, W, H, normal_mode, spp=3, window=None):
 
 def assert_same(res):
     b = res["brute"]
-    for other in ("bvh", "cull", "grid"):
+    for other in ("bvh", "bvh_morton", "cull", "grid"):
         a = res[other]
         assert np.array_equal(a[0], b[0]), f"{other}: {(a[0] != b[0]).sum()} primary ids differ"
         assert n_bit_mismatch(a[1], b[1]) == 0, other
