@@ -252,19 +252,44 @@ __global__ __launch_bounds__(256) void bvh_wide_indices(const int* __restrict__ 
     if (!flag[i]) wide_index[i] = -1;  // (flagged entries hold the exclusive sum = their index)
 }
 
-// Wide node of binary node i: the children of i, an internal child (more triangles than a leaf holds) replaced by ITS two
-// children. Boxes are the ones bvh_emit_nodes pads (same pads, absolute coordinates), rounded outwards to the frame's steps and
-// one step further. A walk decodes a bound as fma(q, step / d, (base - o) / d): its rounding is some 1e-7 of the scene's size in
-// position, a step is 1.5e-5 of it.
-__global__ __launch_bounds__(256) void bvh_emit_wide(const uint32_t* __restrict__ order, const int* __restrict__ child,
+// Children of the wide node made of binary node i, by the fixed rule: the children of i, an internal child (more triangles than a
+// leaf holds) replaced by ITS two children -- every second level of the binary tree disappears.
+__global__ __launch_bounds__(256) void bvh_wide_children(const int* __restrict__ child, const int* __restrict__ range,
+                                                         const int* __restrict__ wide_index, int n, int* __restrict__ wide_child) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1 || wide_index[i] < 0) return;
+    int* out = wide_child + 4 * (size_t)wide_index[i];
+    int slot = 0;
+    for (int c = 0; c < 2; ++c) {
+        const int ref = child[2 * i + c];
+        if (traversal_ref(ref, range, PT_BVH_WIDE_LEAF_MAX) & 0x80000000u) {
+            out[slot++] = ref;
+        } else {
+            out[slot++] = child[2 * ref];
+            out[slot++] = child[2 * ref + 1];
+        }
+    }
+    for (; slot < 4; ++slot) out[slot] = PT_BVH_NO_WIDE_CHILD;
+}
+
+// Wide node of binary node i from its list of children (binary refs). Boxes are the ones bvh_emit_nodes pads (same pads,
+// absolute coordinates), rounded outwards to the frame's steps and one step further. A walk decodes a bound as
+// fma(q, step / d, (base - o) / d): its rounding is some 1e-7 of the scene's size in position, a step is 1.5e-5 of it.
+__global__ __launch_bounds__(256) void bvh_emit_wide(const uint32_t* __restrict__ order, const int* __restrict__ wide_child,
                                                      const int* __restrict__ range, const float* __restrict__ tri_box,
                                                      const float* __restrict__ node_box, const int* __restrict__ wide_index, int n,
                                                      float extra_pad, const float* __restrict__ qframe, uint32_t* __restrict__ nodes_w) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1 || wide_index[i] < 0) return;
     uint32_t* out = nodes_w + (size_t)wide_index[i] * PT_BVH_WNODE_WORDS;
-    int slot = 0;
-    auto put = [&](int ref) {
+    const int* mine = wide_child + 4 * (size_t)wide_index[i];
+    for (int slot = 0; slot < 4; ++slot) {
+        const int ref = mine[slot];
+        if (ref == PT_BVH_NO_WIDE_CHILD) {
+            out[4 * slot] = 0u; out[4 * slot + 1] = 0u; out[4 * slot + 2] = 0u;
+            out[4 * slot + 3] = PT_BVH_NO_CHILD;
+            continue;
+        }
         const float* box = ref < 0 ? tri_box + 6 * (size_t)order[~ref] : node_box + 6 * (size_t)ref;
         float far = 0.f;
         for (int k = 0; k < 6; ++k) far = fmaxf(far, fabsf(box[k]));
@@ -277,20 +302,6 @@ __global__ __launch_bounds__(256) void bvh_emit_wide(const uint32_t* __restrict_
         }
         const uint32_t t = traversal_ref(ref, range, PT_BVH_WIDE_LEAF_MAX);
         out[4 * slot + 3] = (t & 0x80000000u) ? t : (uint32_t)wide_index[ref];
-        ++slot;
-    };
-    for (int c = 0; c < 2; ++c) {
-        const int ref = child[2 * i + c];
-        if (traversal_ref(ref, range, PT_BVH_WIDE_LEAF_MAX) & 0x80000000u) {
-            put(ref);
-        } else {  // an internal node of an odd level: its children stand in for it
-            put(child[2 * ref]);
-            put(child[2 * ref + 1]);
-        }
-    }
-    for (; slot < 4; ++slot) {
-        out[4 * slot] = 0u; out[4 * slot + 1] = 0u; out[4 * slot + 2] = 0u;
-        out[4 * slot + 3] = PT_BVH_NO_CHILD;
     }
 }
 
@@ -437,8 +448,9 @@ struct SahBuilder {
     }
 };
 
-// Boxes bottom-up and the numbering of the wide nodes, for whatever made order / child / range (node 0 is the root).
-hipError_t finish_topology(const PtBvhBuild& b, hipStream_t stream, int32_t* out_passes) {
+// Boxes bottom-up, for whatever made order / child / range (node 0 is the root); and, unless the builder has made its own, the
+// wide nodes by the fixed rule.
+hipError_t finish_topology(const PtBvhBuild& b, hipStream_t stream, int32_t* out_passes, bool number_wide) {
     const int n = b.num_triangles;
     hipError_t e = hipMemsetAsync(b.done, 0, (size_t)(n - 1) * sizeof(int), stream);
     if (e != hipSuccess) return e;
@@ -458,6 +470,7 @@ hipError_t finish_topology(const PtBvhBuild& b, hipStream_t stream, int32_t* out
         if (e != hipSuccess) return e;
     }
     if (out_passes) *out_passes = pass - 1;
+    if (!number_wide) return hipGetLastError();
     // numbering of the wide nodes (every second level)
     hipLaunchKernelGGL(bvh_parents, grid_for(n - 1), dim3(256), 0, stream, b.child, n, b.parent);
     hipLaunchKernelGGL(bvh_wide_flags, grid_for(n - 1), dim3(256), 0, stream, b.parent, b.range, n, b.wide_flag);
@@ -465,6 +478,7 @@ hipError_t finish_topology(const PtBvhBuild& b, hipStream_t stream, int32_t* out
     e = hipcub::DeviceScan::ExclusiveSum(b.sort_tmp, bytes, b.wide_flag, b.wide_index, n - 1, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(bvh_wide_indices, grid_for(n - 1), dim3(256), 0, stream, b.wide_flag, n, b.wide_index);
+    hipLaunchKernelGGL(bvh_wide_children, grid_for(n - 1), dim3(256), 0, stream, b.child, b.range, b.wide_index, n, b.wide_child);
     return hipGetLastError();
 }
 
@@ -523,12 +537,67 @@ hipError_t pt_bvh_build_topology_sah(const PtBvhBuild& b, hipStream_t stream, in
     if (!failed) work();
     for (auto& th : pool) th.join();
     if (failed) return hipErrorOutOfMemory;
+    // Wide nodes: a node's two children, then the child with the largest box replaced by its own two children until there are
+    // four (children that are leaves of the wide form stay). Fewer, tighter nodes than dropping every second level of the binary
+    // tree: the surface-area builder's subtrees are not of equal depth.
+    std::vector<int> wide_index, wide_child;
+    try {
+        const size_t ni = (size_t)(n - 1);
+        std::vector<HostBox> box(ni);
+        auto box_of = [&](int ref, HostBox& out) {
+            if (ref >= 0) { out = box[(size_t)ref]; return; }
+            out.reset();
+            out.add(tri_box.data() + 6 * (size_t)order[(size_t)~ref]);
+        };
+        for (int i = n - 2; i >= 0; --i) {   // (children have larger indices than their parent)
+            HostBox l, r;
+            box_of(child[2 * (size_t)i], l);
+            box_of(child[2 * (size_t)i + 1], r);
+            l.add(r);
+            box[(size_t)i] = l;
+        }
+        auto is_leaf = [&](int ref) { return ref < 0 || range[2 * (size_t)ref + 1] - range[2 * (size_t)ref] + 1 <= PT_BVH_WIDE_LEAF_MAX; };
+        wide_index.assign(ni, -1);
+        wide_child.reserve(ni * 2);
+        std::vector<int> roots;
+        if (!is_leaf(0)) roots.push_back(0);
+        int count = 0;
+        while (!roots.empty()) {
+            const int i = roots.back();
+            roots.pop_back();
+            wide_index[(size_t)i] = count++;
+            int slots[4] = {child[2 * (size_t)i], child[2 * (size_t)i + 1], PT_BVH_NO_WIDE_CHILD, PT_BVH_NO_WIDE_CHILD};
+            int used = 2;
+            while (used < 4) {
+                int pick = -1;
+                float pick_area = -1.0f;
+                for (int k = 0; k < used; ++k)
+                    if (!is_leaf(slots[k])) {
+                        const float a = box[(size_t)slots[k]].half_area();
+                        if (a > pick_area) { pick_area = a; pick = k; }
+                    }
+                if (pick < 0) break;
+                const int ref = slots[pick];
+                slots[pick] = child[2 * (size_t)ref];
+                slots[used++] = child[2 * (size_t)ref + 1];
+            }
+            for (int k = 0; k < 4; ++k) {
+                wide_child.push_back(slots[k]);
+                if (k < used && !is_leaf(slots[k])) roots.push_back(slots[k]);
+            }
+        }
+        wide_child.resize(ni * 4, PT_BVH_NO_WIDE_CHILD);
+    } catch (const std::exception&) {
+        return hipErrorOutOfMemory;
+    }
     e = hipMemcpyAsync(b.order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream);
     if (e == hipSuccess) e = hipMemcpyAsync(b.child, child.data(), child.size() * sizeof(int), hipMemcpyHostToDevice, stream);
     if (e == hipSuccess) e = hipMemcpyAsync(b.range, range.data(), range.size() * sizeof(int), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(b.wide_index, wide_index.data(), wide_index.size() * sizeof(int), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(b.wide_child, wide_child.data(), wide_child.size() * sizeof(int), hipMemcpyHostToDevice, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);   // the host arrays go out of scope
     if (e != hipSuccess) return e;
-    return finish_topology(b, stream, out_passes);
+    return finish_topology(b, stream, out_passes, false);
 }
 
 size_t pt_bvh_sort_temp_bytes(int32_t n) {
@@ -550,7 +619,7 @@ hipError_t pt_bvh_build_topology(const PtBvhBuild& b, hipStream_t stream, int32_
     hipError_t e = hipcub::DeviceRadixSort::SortPairs(b.sort_tmp, bytes, b.keys_tmp, b.keys, b.order_tmp, b.order, n, 0, 63, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(bvh_hierarchy, grid_for(n - 1), dim3(256), 0, stream, b.keys, n, b.child, b.range);
-    return finish_topology(b, stream, out_passes);
+    return finish_topology(b, stream, out_passes, true);
 }
 
 hipError_t pt_bvh_emit(const PtBvhBuild& b, const float ro[3], const float* tris, const float* tris_abs, hipStream_t stream) {
@@ -564,7 +633,7 @@ hipError_t pt_bvh_emit(const PtBvhBuild& b, const float ro[3], const float* tris
         hipLaunchKernelGGL(bvh_emit_nodes, grid_for(n - 1), dim3(256), 0, stream, b.order, b.child, b.range, b.tri_box, b.node_box, n, 0.0f,
                            0.0f, 0.0f, 4.0e-6f * b.scene_scale, b.nodes_abs);
         hipLaunchKernelGGL(bvh_emit_qframe, dim3(1), dim3(64), 0, stream, b.node_box, b.scene_scale, b.qframe);
-        hipLaunchKernelGGL(bvh_emit_wide, grid_for(n - 1), dim3(256), 0, stream, b.order, b.child, b.range, b.tri_box, b.node_box, b.wide_index, n,
+        hipLaunchKernelGGL(bvh_emit_wide, grid_for(n - 1), dim3(256), 0, stream, b.order, b.wide_child, b.range, b.tri_box, b.node_box, b.wide_index, n,
                            4.0e-6f * b.scene_scale, b.qframe, b.nodes_w);
     }
     hipLaunchKernelGGL(bvh_gather_qrecords, grid_for(n + PT_TRI_PAD), dim3(256), 0, stream, b.order, reinterpret_cast<const float4*>(tris_abs), n,

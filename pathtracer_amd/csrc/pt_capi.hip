@@ -265,7 +265,7 @@ void free_target(PtContext* ctx) {
 void free_bvh(PtContext* ctx) {
     PtBvhBuild& b = ctx->bvh;
     void* ptrs[] = {b.tri_box, b.scene_box, b.keys_tmp, b.keys, b.order_tmp, b.order, b.sort_tmp, b.child, b.range, b.node_box, b.done, b.remaining,
-                    b.nodes, b.sorted_tris, b.sorted_ids, b.nodes_abs, b.sorted_tris_abs, b.nodes_w, b.tris_q, b.qframe, b.parent, b.wide_index, b.wide_flag};
+                    b.nodes, b.sorted_tris, b.sorted_ids, b.nodes_abs, b.sorted_tris_abs, b.nodes_w, b.tris_q, b.qframe, b.parent, b.wide_index, b.wide_flag, b.wide_child};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     b = PtBvhBuild{};
@@ -914,6 +914,7 @@ PtStatus pt_build_accel(PtContext* ctx) {
     alloc(&b.parent, ni * sizeof(int));
     alloc(&b.wide_index, ni * sizeof(int));
     alloc(&b.wide_flag, ni * sizeof(int));
+    alloc(&b.wide_child, ni * 4 * sizeof(int));
     alloc(&b.tris_q, (nn + PT_TRI_PAD) * PT_BVH_QTRI_FLOATS * sizeof(float));
     alloc(&b.qframe, 8 * sizeof(float));
     if (e == hipSuccess)

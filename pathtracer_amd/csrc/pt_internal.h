@@ -40,6 +40,7 @@ struct PtTriRecordLayout {
 #define PT_BVH_WIDE_LEAF_MAX 2  // triangles per leaf of the wide form (1M triangles: 11.1 ms at 2, 11.3 at 1, 11.8 at 4)
 #endif
 #define PT_BVH_NO_CHILD 0xffffffffu
+#define PT_BVH_NO_WIDE_CHILD ((int)0x80000000)  // in PtBvhBuild::wide_child (no leaf position reaches ~INT_MIN)
 #define PT_BVH_QTRI_FLOATS 12
 #ifndef PT_BVH_LEAF_MAX
 #define PT_BVH_LEAF_MAX 4
@@ -80,6 +81,7 @@ struct PtBvhBuild {
     int* parent;                  // (n-1): binary parent of each internal node (-1 for the root)
     int* wide_index;              // (n-1): index of the wide node made of this binary node, or -1 (odd level, or inside a leaf)
     int* wide_flag;               // (n-1): scratch of the numbering
+    int* wide_child;              // (n-1) x 4: binary refs of each wide node's children (PT_BVH_NO_WIDE_CHILD: slot unused)
     uint32_t* nodes_w;            // up to (n-1) x PT_BVH_WNODE_WORDS: wide nodes, absolute boxes in 16-bit steps of the frame
     float* tris_q;                // (n + PT_TRI_PAD) x PT_BVH_QTRI_FLOATS: a, e1, e2, id in leaf order
     float* qframe;                // 8: base xyz, step xyz of the frame, -, -
