@@ -18,6 +18,8 @@ def main():
     ap.add_argument("--reps", type=int, default=4)
     ap.add_argument("--shading", default="materials")
     ap.add_argument("--accel", default="auto")
+    ap.add_argument("--lib", default=None, help="a variant library (pathtracer_amd.build.build_hip(tag=...))")
+    ap.add_argument("--builders", default="morton,sah")
     args = ap.parse_args()
     from pathtracer_amd import Tracer, capi
     from pathtracer_amd.scenes import SceneData
@@ -26,9 +28,9 @@ def main():
         spp = int(spp)
         scene = SceneData(wl, None, None)
         digests = {}
-        for builder in ("morton", "sah"):
+        for builder in args.builders.split(","):
             os.environ["PT_BVH_BUILDER"] = builder
-            t = Tracer(0)
+            t = Tracer(0, args.lib)
             with t:
                 scene.upload(t, shading=args.shading, accel=False)
                 t.target_create(scene.width, scene.height)
@@ -58,7 +60,7 @@ def main():
                                   "dispatch_ms": ms, "steps_per_traced_ray": st["grid_triangle_tests"] / max(1, st["rays_traced"]),
                                   "triangle_records_per_traced_ray": st["lane_walk_records"] / max(1, st["rays_traced"]),
                                   "wave_walk_nodes": st["bvh_node_fetches"], "self_check": [compared, bad_id, bad_t]}), flush=True)
-        print(json.dumps({"workload": wl, "images_equal": digests["morton"] == digests["sah"]}), flush=True)
+        print(json.dumps({"workload": wl, "images_equal": len(set(digests.values())) == 1, "sha256": sorted(set(digests.values()))[0][:16]}), flush=True)
 
 
 if __name__ == "__main__":
