@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <array>
 #include <atomic>
+#include <cstring>
 #include <thread>
 #include <vector>
 
@@ -414,12 +415,20 @@ struct SahBuilder {
         int k = 0;
         for (int a = 1; a < 3; ++a) if (chi[a] - clo[a] > chi[k] - clo[k]) k = a;
         const int at = first + count / 2;
-        if (chi[k] > clo[k])
+        if (chi[k] > clo[k]) {
+            // (compared through their bit patterns, which are totally ordered whatever the values: a mesh may hold NaNs)
+            auto key = [&](uint32_t id) {
+                const float* b = tri_box + 6 * (size_t)id;
+                const float c = 0.5f * b[k] + 0.5f * b[3 + k];
+                uint32_t u;
+                memcpy(&u, &c, sizeof u);
+                return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+            };
             std::nth_element(order + first, order + at, order + last + 1, [&](uint32_t x, uint32_t y) {
-                const float* bx = tri_box + 6 * (size_t)x; const float* by = tri_box + 6 * (size_t)y;
-                const float cx = 0.5f * bx[k] + 0.5f * bx[3 + k], cy = 0.5f * by[k] + 0.5f * by[3 + k];
-                return cx < cy || (cx == cy && x < y);
+                const uint32_t kx = key(x), ky = key(y);
+                return kx < ky || (kx == ky && x < y);
             });
+        }
         return at;
     }
 

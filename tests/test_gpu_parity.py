@@ -162,8 +162,8 @@ def test_materials_mode_random_scene_against_oracle(tracer, wave_walk_tracer, ac
 
 def _awkward_meshes():
     """Layouts that stress the four-child hierarchy with 16-bit boxes: no extent along an axis, a few tiny triangles very far from
-    a dense cluster (a frame step is then larger than the cluster's triangles), every triangle the same, and triangle counts just
-    above what one leaf holds."""
+    a dense cluster (a frame step is then larger than the cluster's triangles), every triangle the same, triangles with NaN
+    coordinates (never hit, and they must not upset a builder), and triangle counts just above what one leaf holds."""
     rng = np.random.default_rng(23)
     out = {}
     g = 24
@@ -182,12 +182,17 @@ def _awkward_meshes():
     out["spread"] = np.concatenate([cluster, far, big]).astype(np.float32)
     one = np.array([[[-1, -1, 6.0], [0, 1, 6.0], [1, -1, 6.0]]], np.float32)
     out["same"] = np.repeat(one, 37, axis=0)
+    holes = (rng.uniform(-1, 1, (300, 1, 3)) * 0.8 + np.array([0, 0, 6.0]) + rng.uniform(-0.2, 0.2, (300, 3, 3))).astype(np.float32)
+    holes[7, 1, 0] = np.nan                                                  # one coordinate, one corner, whole triangles
+    holes[50, 2] = np.nan
+    holes[120:124] = np.nan
+    out["nan"] = holes
     for n in (3, 5, 9):
         out[f"few{n}"] = (rng.uniform(-1.5, 1.5, (n, 1, 3)) + np.array([0, 0, 6.0]) + rng.uniform(-1.0, 1.0, (n, 3, 3))).astype(np.float32)
     return out
 
 
-@pytest.mark.parametrize("layout", ["flat", "spread", "same", "few3", "few5", "few9"])
+@pytest.mark.parametrize("layout", ["flat", "spread", "same", "nan", "few3", "few5", "few9"])
 def test_materials_walk_on_awkward_layouts(tracer, layout):
     """The decoupled walk over the four-child form against the loop over all triangles, image and ray count bit for bit, and the
     device-side self-check of the form, on layouts chosen against its box encoding."""
