@@ -204,7 +204,7 @@ PtStatus pt_build_accel(PtContext* ctx);
  * could not accept); the time of the walks and of the build does. */
 typedef enum PtBvhBuilder {
     PT_BVH_BUILDER_SAH = 0,    /* default: top-down on the host, splits by the binned surface-area heuristic, up to 16 threads;
-                                  0.1 s for a million triangles; its walks fetch 10-20 % fewer records */
+                                  0.09 s for a million triangles; its walks fetch 10-20 % fewer records */
     PT_BVH_BUILDER_MORTON = 1  /* on the device: Morton codes, radix sort, Karras hierarchy; 11 ms for a million triangles --
                                   for meshes that are rebuilt often */
 } PtBvhBuilder;

@@ -12,7 +12,11 @@
 #include <algorithm>
 #include <array>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <thread>
 #include <vector>
 
@@ -354,8 +358,10 @@ struct SahBuilder {
     // where the range [first, last] is cut: the first position of its right part
     int split(int first, int last) const {
         const int count = last - first + 1;
+        // a large range picks its plane from every stride-th triangle (16,384 or more of them); all of them are then partitioned
+        const int stride = count >= (1 << 17) ? count >> 14 : 1;
         float clo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, chi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-        for (int p = first; p <= last; ++p) {
+        for (int p = first; p <= last; p += stride) {
             const float* b = tri_box + 6 * (size_t)order[p];
             for (int k = 0; k < 3; ++k) {
                 const float c = 0.5f * b[k] + 0.5f * b[3 + k];
@@ -372,7 +378,8 @@ struct SahBuilder {
                 scale[k] = chi[k] > clo[k] ? (float)kBins / (chi[k] - clo[k]) : 0.f;
                 for (int j = 0; j < kBins; ++j) { bins[k][j].reset(); counts[k][j] = 0; }
             }
-            for (int p = first; p <= last; ++p) {
+            int sampled = 0;
+            for (int p = first; p <= last; p += stride, ++sampled) {
                 const float* b = tri_box + 6 * (size_t)order[p];
                 for (int k = 0; k < 3; ++k) {
                     const float c = 0.5f * b[k] + 0.5f * b[3 + k];
@@ -395,8 +402,8 @@ struct SahBuilder {
                 for (int j = 0; j + 1 < kBins; ++j) {
                     if (counts[k][j]) acc.add(bins[k][j]);
                     left += counts[k][j];
-                    if (left == 0 || left == count) continue;
-                    const float cost = acc.half_area() * (float)left + right_area[j + 1] * (float)(count - left);
+                    if (left == 0 || left == sampled) continue;
+                    const float cost = acc.half_area() * (float)left + right_area[j + 1] * (float)(sampled - left);
                     if (cost < best_cost) { best_cost = cost; best_axis = k; best_bin = j; }
                 }
             }
@@ -515,67 +522,80 @@ hipError_t pt_bvh_build_topology_sah(const PtBvhBuild& b, hipStream_t stream, in
     e = hipStreamSynchronize(stream);
     if (e != hipSuccess) return e;
     for (int i = 0; i < n; ++i) order[(size_t)i] = (uint32_t)i;
+    const bool report = getenv("PT_DEBUG_SCHED") != nullptr;
+    auto now = []() { return std::chrono::steady_clock::now(); };
+    auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
+    const auto t_start = now();
+    double ms_top = 0.0, ms_subtrees = 0.0, ms_wide = 0.0;
     SahBuilder sb{tri_box.data(), order.data(), child.data(), range.data()};
-    // The top of the tree on this thread, down to subtrees of at most n / 64 triangles; those are shared out among this thread and
-    // up to 15 more (they work on disjoint parts of every array, and a subtree's node indices follow from its position, so the
-    // result does not depend on which thread built what). Threads that cannot be started are done without.
-    std::vector<std::array<int, 3>> parts;
-    std::atomic<size_t> next{0};
-    std::atomic<bool> failed{false};
-    auto work = [&]() {
-        try {
-            for (size_t k = next.fetch_add(1); k < parts.size(); k = next.fetch_add(1)) sb.build(parts[k][0], parts[k][1], parts[k][2], nullptr, 0);
-        } catch (const std::exception&) {
-            failed = true;
-        }
-    };
-    std::vector<std::thread> pool;
-    try {
-        const int threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-        sb.build(0, 0, n - 1, threads > 1 && n >= 4096 ? &parts : nullptr, std::max(2, n / 64));
-        if (!parts.empty()) {
-            pool.reserve((size_t)threads);
+    // Work that falls into independent pieces is shared out among this thread and up to 15 more. Threads that cannot be started
+    // are done without. Returns false when a piece ran out of memory.
+    const int threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    auto parallel_for = [threads](size_t pieces, const std::function<void(size_t)>& piece) {
+        std::atomic<size_t> next{0};
+        std::atomic<bool> failed{false};
+        auto work = [&]() {
             try {
-                for (int t = 1; t < threads; ++t) pool.emplace_back(work);
+                for (size_t k = next.fetch_add(1); k < pieces; k = next.fetch_add(1)) piece(k);
             } catch (const std::exception&) {
+                failed = true;
             }
+        };
+        std::vector<std::thread> pool;
+        try {
+            pool.reserve((size_t)threads);
+            for (int t = 1; t < threads && (size_t)t < pieces; ++t) pool.emplace_back(work);
+        } catch (const std::exception&) {
         }
+        work();
+        for (auto& th : pool) th.join();
+        return !failed;
+    };
+    // The top of the tree on this thread, down to subtrees of at most n / 64 triangles; then the subtrees, which work on disjoint
+    // parts of every array (a subtree's node indices follow from its position, so the result does not depend on which thread
+    // built what).
+    std::vector<std::array<int, 3>> parts;   // node, first, last
+    try {
+        sb.build(0, 0, n - 1, threads > 1 && n >= 4096 ? &parts : nullptr, std::max(2, n / 64));
     } catch (const std::exception&) {
-        failed = true;
+        return hipErrorOutOfMemory;
     }
-    if (!failed) work();
-    for (auto& th : pool) th.join();
-    if (failed) return hipErrorOutOfMemory;
+    ms_top = ms_since(t_start);
+    if (!parallel_for(parts.size(), [&](size_t k) { sb.build(parts[k][0], parts[k][1], parts[k][2], nullptr, 0); })) return hipErrorOutOfMemory;
+    ms_subtrees = ms_since(t_start) - ms_top;
+    const auto t_wide = now();
     // Wide nodes: a node's two children, then the child with the largest box replaced by its own two children until there are
     // four (children that are leaves of the wide form stay). Fewer, tighter nodes than dropping every second level of the binary
-    // tree: the surface-area builder's subtrees are not of equal depth.
+    // tree: the surface-area builder's subtrees are not of equal depth. Numbered depth first: the top of the tree, then one block
+    // per wide node found inside a subtree of the list above (those blocks are made side by side).
     std::vector<int> wide_index, wide_child;
+    int wide_count = 0;
     try {
         const size_t ni = (size_t)(n - 1);
         std::vector<HostBox> box(ni);
-        auto box_of = [&](int ref, HostBox& out) {
-            if (ref >= 0) { out = box[(size_t)ref]; return; }
-            out.reset();
-            out.add(tri_box.data() + 6 * (size_t)order[(size_t)~ref]);
+        std::vector<uint8_t> in_part(ni, 0);
+        auto node_box = [&](int i) {   // (children have larger indices than their parent)
+            HostBox both;
+            both.reset();
+            for (int c = 0; c < 2; ++c) {
+                const int ref = child[2 * (size_t)i + c];
+                if (ref >= 0) both.add(box[(size_t)ref]);
+                else both.add(tri_box.data() + 6 * (size_t)order[(size_t)~ref]);
+            }
+            box[(size_t)i] = both;
         };
-        for (int i = n - 2; i >= 0; --i) {   // (children have larger indices than their parent)
-            HostBox l, r;
-            box_of(child[2 * (size_t)i], l);
-            box_of(child[2 * (size_t)i + 1], r);
-            l.add(r);
-            box[(size_t)i] = l;
-        }
+        if (!parallel_for(parts.size(), [&](size_t k) {
+                const int lo = parts[k][0], hi = parts[k][0] + (parts[k][2] - parts[k][1]) - 1;   // a subtree over c triangles: c - 1 nodes
+                for (int i = hi; i >= lo; --i) { node_box(i); in_part[(size_t)i] = 1; }
+            }))
+            return hipErrorOutOfMemory;
+        for (int i = n - 2; i >= 0; --i)
+            if (!in_part[(size_t)i]) node_box(i);
         auto is_leaf = [&](int ref) { return ref < 0 || range[2 * (size_t)ref + 1] - range[2 * (size_t)ref] + 1 <= PT_BVH_WIDE_LEAF_MAX; };
-        wide_index.assign(ni, -1);
-        wide_child.reserve(ni * 2);
-        std::vector<int> roots;
-        if (!is_leaf(0)) roots.push_back(0);
-        int count = 0;
-        while (!roots.empty()) {
-            const int i = roots.back();
-            roots.pop_back();
-            wide_index[(size_t)i] = count++;
-            int slots[4] = {child[2 * (size_t)i], child[2 * (size_t)i + 1], PT_BVH_NO_WIDE_CHILD, PT_BVH_NO_WIDE_CHILD};
+        // children of the wide node rooted at binary node i -> slots; returns how many
+        auto expand = [&](int i, int* slots) {
+            slots[0] = child[2 * (size_t)i]; slots[1] = child[2 * (size_t)i + 1];
+            slots[2] = slots[3] = PT_BVH_NO_WIDE_CHILD;
             int used = 2;
             while (used < 4) {
                 int pick = -1;
@@ -590,15 +610,57 @@ hipError_t pt_bvh_build_topology_sah(const PtBvhBuild& b, hipStream_t stream, in
                 slots[pick] = child[2 * (size_t)ref];
                 slots[used++] = child[2 * (size_t)ref + 1];
             }
-            for (int k = 0; k < 4; ++k) {
-                wide_child.push_back(slots[k]);
-                if (k < used && !is_leaf(slots[k])) roots.push_back(slots[k]);
-            }
+            return used;
+        };
+        wide_index.assign(ni, -1);
+        wide_child.assign(ni * 4, PT_BVH_NO_WIDE_CHILD);
+        std::vector<int> roots, deferred;
+        if (!is_leaf(0)) roots.push_back(0);
+        while (!roots.empty()) {
+            const int i = roots.back();
+            roots.pop_back();
+            if (in_part[(size_t)i]) { deferred.push_back(i); continue; }
+            int slots[4];
+            const int used = expand(i, slots);
+            wide_index[(size_t)i] = wide_count;
+            for (int k = 0; k < 4; ++k) wide_child[4 * (size_t)wide_count + k] = slots[k];
+            ++wide_count;
+            for (int k = 0; k < used; ++k)
+                if (!is_leaf(slots[k])) roots.push_back(slots[k]);
         }
-        wide_child.resize(ni * 4, PT_BVH_NO_WIDE_CHILD);
+        struct Block { std::vector<int> nodes, children; };
+        std::vector<Block> blocks(deferred.size());
+        if (!parallel_for(deferred.size(), [&](size_t d) {
+                Block& blk = blocks[d];
+                std::vector<int> todo{deferred[d]};
+                while (!todo.empty()) {
+                    const int i = todo.back();
+                    todo.pop_back();
+                    int slots[4];
+                    const int used = expand(i, slots);
+                    blk.nodes.push_back(i);
+                    blk.children.insert(blk.children.end(), slots, slots + 4);
+                    for (int k = 0; k < used; ++k)
+                        if (!is_leaf(slots[k])) todo.push_back(slots[k]);
+                }
+            }))
+            return hipErrorOutOfMemory;
+        std::vector<int> base(deferred.size() + 1, wide_count);
+        for (size_t d = 0; d < deferred.size(); ++d) base[d + 1] = base[d] + (int)blocks[d].nodes.size();
+        wide_count = base[deferred.size()];
+        if (!parallel_for(deferred.size(), [&](size_t d) {
+                const Block& blk = blocks[d];
+                for (size_t q = 0; q < blk.nodes.size(); ++q) {
+                    wide_index[(size_t)blk.nodes[q]] = base[d] + (int)q;
+                    for (int k = 0; k < 4; ++k) wide_child[4 * ((size_t)base[d] + q) + k] = blk.children[4 * q + k];
+                }
+            }))
+            return hipErrorOutOfMemory;
     } catch (const std::exception&) {
         return hipErrorOutOfMemory;
     }
+    ms_wide = ms_since(t_wide);
+    const auto t_upload = now();
     e = hipMemcpyAsync(b.order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream);
     if (e == hipSuccess) e = hipMemcpyAsync(b.child, child.data(), child.size() * sizeof(int), hipMemcpyHostToDevice, stream);
     if (e == hipSuccess) e = hipMemcpyAsync(b.range, range.data(), range.size() * sizeof(int), hipMemcpyHostToDevice, stream);
@@ -606,6 +668,9 @@ hipError_t pt_bvh_build_topology_sah(const PtBvhBuild& b, hipStream_t stream, in
     if (e == hipSuccess) e = hipMemcpyAsync(b.wide_child, wide_child.data(), wide_child.size() * sizeof(int), hipMemcpyHostToDevice, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);   // the host arrays go out of scope
     if (e != hipSuccess) return e;
+    if (report)
+        fprintf(stderr, "[pt bvh] host builder, %d triangles: top of the tree %.1f ms, subtrees %.1f ms, wide nodes %.1f ms, upload %.1f ms\n", n,
+                ms_top, ms_subtrees, ms_wide, ms_since(t_upload));
     return finish_topology(b, stream, out_passes, false);
 }
 
