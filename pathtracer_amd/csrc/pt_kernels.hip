@@ -37,11 +37,11 @@ __device__ __forceinline__ float ieee_rcp(float x) {
     return __builtin_amdgcn_div_fixupf(q, x, 1.0f);
 }
 // sqrtf(x), correctly rounded: the compiler's own refinement (reciprocal square root, coupled Newton step, residual
-// correction) without its rescaling of tiny inputs, which take the compiler's full sequence instead. Bit-identical to
-// __builtin_sqrtf for all 2^32 inputs (pt_arith_selftest_kernel).
+// correction) without its rescaling of tiny inputs and without its selects for 0 and infinity: finite inputs from 2^-96 up take
+// this way (one unsigned compare decides), every other bit pattern (zeros, tiny, negative, infinite, NaN -- rare on the render
+// path) takes the compiler's full sequence. Bit-identical to __builtin_sqrtf for all 2^32 inputs (pt_arith_selftest_kernel).
 __device__ __forceinline__ float ieee_sqrt(float x) {
-    const uint32_t xb = __float_as_uint(x);  // the short way serves +-0 and [2^-96, +inf] and NaN; the rest (tiny, negative) is rare
-    if ((xb - 0x0f800000u) >= 0x70800000u && (xb << 1) != 0u) return __builtin_sqrtf(x);
+    if ((__float_as_uint(x) - 0x0f800000u) >= 0x70000000u) return __builtin_sqrtf(x);
     const float r = __builtin_amdgcn_rsqf(x);
     float s = x * r;
     float h = 0.5f * r;
@@ -49,8 +49,7 @@ __device__ __forceinline__ float ieee_sqrt(float x) {
     s = __builtin_fmaf(s, e, s);
     h = __builtin_fmaf(h, e, h);
     const float d = __builtin_fmaf(-s, s, x);
-    s = __builtin_fmaf(d, h, s);
-    return (x == 0.0f || x == __builtin_inff()) ? x : s;
+    return __builtin_fmaf(d, h, s);
 }
 __device__ __forceinline__ v3 normalize3(v3 a) { return a * ieee_rcp(ieee_sqrt(dot3(a, a))); }
 __device__ __forceinline__ v3 reflect3(v3 i, v3 n) { return i - n * (2.0f * dot3(n, i)); }
@@ -89,9 +88,12 @@ __device__ __forceinline__ float lp_sincos(float a) {
 }
 
 // exp2: split into floor and fraction, degree-5 polynomial on the fraction evaluated as even/odd Horner chains.
+// CLAMP_HIGH / CLAMP_LOW: the clamps to 128 and -126.99999; a caller whose argument cannot reach a bound leaves that clamp out
+// (the result is the same for every argument inside the bound; pt_arith_selftest_kernel compares the forms over the ranges used).
+template <bool CLAMP_HIGH = true, bool CLAMP_LOW = true>
 __device__ __forceinline__ float lp_exp2(float x) {
-    x = __builtin_fminf(128.0f, x);
-    x = __builtin_fmaxf(-126.99999f, x);
+    if (CLAMP_HIGH) x = __builtin_fminf(128.0f, x);
+    if (CLAMP_LOW) x = __builtin_fmaxf(-126.99999f, x);
     const float ip = __builtin_floorf(x);
     const float f = x - ip;
     const float e = __uint_as_float((uint32_t)(((int32_t)ip + 127) << 23));
@@ -114,6 +116,9 @@ __device__ __forceinline__ float log2_quotient(float m) {
 }
 
 // log2: exponent + y*P(y^2) with y = (m-1)/(m+1), m the mantissa in [1,2); degree-4 P.
+// UNIT: the argument is a rand01() result, i.e. in [0, 1) or NaN: of the three special cases only x == 0 can occur (a NaN fails
+// all three comparisons either way), so the other two selects are left out.
+template <bool UNIT = false>
 __device__ __forceinline__ float lp_log2(float x) {
     const uint32_t i = __float_as_uint(x);
     const float e = (float)((int32_t)((i & 0x7f800000u) >> 23) - 127);
@@ -125,12 +130,15 @@ __device__ __forceinline__ float lp_log2(float x) {
     even = __builtin_fmaf(z2, even, 2.88539009343309178325f);
     float odd = __builtin_fmaf(z2, 0.403343858251329912514f, 0.961791550404184197881f);
     float r = __builtin_fmaf(y, __builtin_fmaf(odd, z, even), e);
-    if (x >= __builtin_inff()) r = __builtin_inff();
+    if (!UNIT && x >= __builtin_inff()) r = __builtin_inff();
     if (x == 0.0f) r = -__builtin_inff();
-    if (x < 0.0f) r = __builtin_nanf("");
+    if (!UNIT && x < 0.0f) r = __builtin_nanf("");
     return r;
 }
 __device__ __forceinline__ float lp_pow(float x, float y) { return lp_exp2(lp_log2(x) * y); }
+// pow(x, y) for x = a rand01() result and 0 < y <= 1 (the two calls of the shading code): log2(x) is -inf or a finite value
+// <= 0 (for a NaN x: the finite value its bits give, below 130), so the product never comes near the upper clamp.
+__device__ __forceinline__ float lp_pow_unit(float x, float y) { return lp_exp2<false, true>(lp_log2<true>(x) * y); }
 
 // ---- the shader's random numbers (fs:21-42) -------------------------------------------------------------
 struct Rng {
@@ -143,7 +151,9 @@ struct Rng {
         const float ay = (fcy + sx) + samples;
         const float r = fract1(52.9829189f * fract1(ax * 0.06711056f + ay * 0.00583715f));
         sx = sx + r;
-        return r - __builtin_floorf(r);
+        // fs:41, mod(r, 1.0) = r - floor(r), leaves r as it is: r is x - floor(x) of a product of 52.98 and a value in [0, 1],
+        // which is exact and below 1 for every such x (a NaN stays the same NaN); pt_arith_selftest_kernel checks every input
+        return r;
     }
 };
 
@@ -597,8 +607,9 @@ __device__ __forceinline__ Hit intersect_grid(const PtKernelParams& p, v3 rd, un
     const int res = p.grid_res;
     const float half = 0.5f * (float)res;
     int iu = (int)__builtin_floorf((fu * iw + 1.0f) * half), iv = (int)__builtin_floorf((fv * iw + 1.0f) * half);
-    iu = iu < 0 ? 0 : (iu >= res ? res - 1 : iu);
-    iv = iv < 0 ? 0 : (iv >= res ? res - 1 : iv);
+    // clamp to [0, res - 1] (res >= 1): the median of the three, one instruction each
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(iu) : "v"(iu), "s"(res - 1));
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(iv) : "v"(iv), "s"(res - 1));
     // < 6 * 2048^2; both factors of either product are below 2^24, so the full-rate 24-bit multiply is exact
     const uint32_t cell = __umul24(__umul24((uint32_t)face, (uint32_t)res) + (uint32_t)iv, (uint32_t)res) + (uint32_t)iu;
     // Open scenes: one bit per 4x4 block of cells says whether anything lies that way at all (read from a table small enough to
@@ -704,7 +715,7 @@ __device__ __forceinline__ void shade(Rng& rng, float& energy, v3& rd, v3 N) {
     const v3 tangent = normalize3(cross3(R, helper));
     const v3 binormal = normalize3(cross3(R, tangent));
     // randomHemisphere(r1, alpha), fs:67-76
-    const float cos_t = lp_pow(r1, 1.0f / (alpha + 1.0f));
+    const float cos_t = lp_pow_unit(r1, 1.0f / (alpha + 1.0f));
     const float sin_t = ieee_sqrt(__builtin_fmaxf(0.0f, 1.0f - cos_t * cos_t));
     const float phi = (rng.rand01() * 2.0f) * 3.141592653589f;
     const v3 hemi = V(lp_sincos<true>(phi) * sin_t, cos_t, lp_sincos<false>(phi) * sin_t);
@@ -712,7 +723,8 @@ __device__ __forceinline__ void shade(Rng& rng, float& energy, v3& rd, v3 N) {
     rd = (tangent * hemi.x + R * hemi.y) + binormal * hemi.z;
     const float diffuse = __builtin_fminf(1.0f - specularity, 0.5f);
     const float f = (alpha + 2.0f) / (alpha + 1.0f);
-    const float fresnel = specularity + (1.0f - specularity) * lp_exp2(-8.656170f * clamp01(dot3(N, rd)));
+    // the exponent lies in [-8.66, 0] whatever dot(N, rd) is (clamp01 maps a NaN to 0): neither clamp of exp2 can bind
+    const float fresnel = specularity + (1.0f - specularity) * lp_exp2<false, false>(-8.656170f * clamp01(dot3(N, rd)));
     const float specular = (fresnel * specularity) * clamp01(dot3(N, rd) * f);
     energy = energy * (diffuse + specular);
 }
@@ -744,7 +756,7 @@ __device__ __forceinline__ void shade_materials(Rng& rng, const float* __restric
         if (__builtin_fabsf(N.x) > 0.99f) helper = V(0.0f, 0.0f, 1.0f);
         const v3 tangent = normalize3(cross3(N, helper));
         const v3 binormal = normalize3(cross3(N, tangent));
-        const float cos_t = lp_pow(r1, 1.0f / (1.0f + 1.0f));
+        const float cos_t = lp_pow_unit(r1, 1.0f / (1.0f + 1.0f));
         const float sin_t = ieee_sqrt(__builtin_fmaxf(0.0f, 1.0f - cos_t * cos_t));
         const float phi = (rng.rand01() * 2.0f) * 3.141592653589f;
         const v3 hemi = V(lp_sincos<true>(phi) * sin_t, cos_t, lp_sincos<false>(phi) * sin_t);
@@ -1675,8 +1687,9 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_verify_kernel(const PtKern
 }
 
 // The short reciprocal, square-root and log2-quotient sequences against the compiler's IEEE division and square root, for
-// every float bit pattern: bad[0] reciprocal, bad[1] square root, bad[2] quotient -- inputs whose results differ in any
-// bit (NaN payloads included). All three must stay 0.
+// every float bit pattern: bad[0] reciprocal, bad[1] square root, bad[2] quotient and the restricted-domain forms (rand01's
+// tail, pow of a value in [0, 1), exp2 without clamps) -- inputs whose results differ in any bit (NaN payloads included). All
+// three must stay 0.
 __global__ __launch_bounds__(256) void pt_arith_selftest_kernel(unsigned long long* __restrict__ bad) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     unsigned b0 = 0, b1 = 0, b2 = 0;
@@ -1687,6 +1700,20 @@ __global__ __launch_bounds__(256) void pt_arith_selftest_kernel(unsigned long lo
         if (i < (1ull << 23)) {
             const float m = __uint_as_float((uint32_t)i | 0x3f800000u);
             b2 += __float_as_uint(log2_quotient(m)) != __float_as_uint((m - 1.0f) / (m + 1.0f));
+        }
+        // the forms that leave out what their callers' arguments cannot reach, against the full forms:
+        // the tail of rand01() for every value the inner expression can take,
+        const float r = fract1(52.9829189f * fract1(x));
+        b2 += __float_as_uint(r - __builtin_floorf(r)) != __float_as_uint(r);
+        // pow of a rand01() result (in [0, 1), or NaN) with the two exponents the shading code uses,
+        if (x != x || (x >= 0.0f && x < 1.0f)) {
+            b2 += __float_as_uint(lp_pow_unit(x, 1.0f / 1025.0f)) != __float_as_uint(lp_pow(x, 1.0f / 1025.0f));
+            b2 += __float_as_uint(lp_pow_unit(x, 0.5f)) != __float_as_uint(lp_pow(x, 0.5f));
+        }
+        // and exp2 without its clamps over the exponents of the Fresnel term: -8.656170 * c for every c in [0, 1]
+        if (x >= 0.0f && x <= 1.0f) {
+            const float a = -8.656170f * x;
+            b2 += __float_as_uint(lp_exp2<false, false>(a)) != __float_as_uint(lp_exp2(a));
         }
     }
     if (b0) atomicAdd(&bad[0], (unsigned long long)b0);

@@ -15,6 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 VARIANTS = {
+    "head": None,   # the kernel sources as committed (git show HEAD:...), to compare the working tree ("base") against
     "base": [],
     "vfirst": ["-DPT_V_VFIRST"],
     "nosky": ["-DPT_V_NO_SKY"],
@@ -23,6 +24,23 @@ VARIANTS = {
     "nounroll": ["-fno-unroll-loops"],
     "o2": ["-O2"],
 }
+
+
+def build_committed(ptbuild, tag):
+    """Compiles the HIP library from the sources of the last commit into libpt_hip__<tag>.so."""
+    import subprocess
+    import tempfile
+    out = os.path.join(ptbuild.LIB, f"libpt_hip__{tag}.so")
+    with tempfile.TemporaryDirectory() as tmp:
+        csrc = os.path.join(tmp, "pathtracer_amd", "csrc")   # same relative layout: the sources include ../../include/pt_hip.h
+        os.makedirs(csrc)
+        os.makedirs(os.path.join(tmp, "include"))
+        names = ["pt_kernels.hip", "pt_bvh.hip", "pt_grid.hip", "pt_capi.hip", "pt_internal.h"]
+        for f in names:
+            open(os.path.join(csrc, f), "wb").write(subprocess.check_output(["git", "-C", ROOT, "show", f"HEAD:pathtracer_amd/csrc/{f}"]))
+        open(os.path.join(tmp, "include", "pt_hip.h"), "wb").write(subprocess.check_output(["git", "-C", ROOT, "show", "HEAD:include/pt_hip.h"]))
+        subprocess.check_call([ptbuild.HIPCC] + ptbuild.DEVICE_FLAGS + ["-shared", "-o", out] + [os.path.join(csrc, f) for f in names[:4]])
+    return out
 
 
 def main():
@@ -40,7 +58,10 @@ def main():
     names = [v for v in VARIANTS if not args.only or v in args.only.split(",")]
     if args.build:
         for v in names:
-            print(ptbuild.build_hip(force=True, extra_flags=VARIANTS[v], tag=v))
+            if VARIANTS[v] is None:
+                print(build_committed(ptbuild, v))
+            else:
+                print(ptbuild.build_hip(force=True, extra_flags=VARIANTS[v], tag=v))
         return
     import numpy as np
     from pathtracer_amd import Tracer
