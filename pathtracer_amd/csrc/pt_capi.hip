@@ -519,8 +519,12 @@ PtStatus fill_params(PtContext* ctx, PtKernelParams* p, const Program** prog_out
                    "the BVH covers all %d triangles but u_NumTriangles = %d",
                    ctx->num_triangles, u.num_triangles);
         p->shading_mode = (int32_t)ctx->shading_mode;
+        // (the grid's query forms the byte offset of a 64-byte triangle record in 32 bits: meshes of at most 2^26 triangles)
+        PT_REQUIRE(ctx->accel_mode != PT_ACCEL_GRID || u.num_triangles <= (1 << 26), PT_ERR_INVALID_ARGUMENT,
+                   "PT_ACCEL_GRID serves meshes of at most %d triangles (this one: %d)", 1 << 26, u.num_triangles);
         const bool grid_possible = ctx->grid_wanted && ctx->shading_mode == PT_SHADE_REFERENCE && u.num_triangles == ctx->num_triangles &&
-                                   u.num_triangles > 0 && (ctx->accel_mode == PT_ACCEL_GRID || (ctx->accel_mode == PT_ACCEL_AUTO && ctx->auto_grid));
+                                   u.num_triangles > 0 && u.num_triangles <= (1 << 26) &&
+                                   (ctx->accel_mode == PT_ACCEL_GRID || (ctx->accel_mode == PT_ACCEL_AUTO && ctx->auto_grid));
         if (grid_possible) {
             PtStatus gs = ensure_grid(ctx);
             if (gs != PT_OK) return gs;

@@ -587,13 +587,20 @@ __device__ __forceinline__ Hit intersect_bvh_lanes(const PtKernelParams& p, v3 r
     }
 }
 
+// A word of one of the direction grid's tables. The byte offset is formed in 32 bits and added to the (wave-uniform) base by
+// the load itself: the tables stay below 4 GiB (6 * 2048^2 cell words; at most 2^30 list words).
+__device__ __forceinline__ uint32_t grid_word(const uint32_t* __restrict__ table, uint32_t index) {
+    return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(table) + (index << 2));
+}
+
 // Direction-grid query (see pt_grid.hip): the cell of the ray's direction lists the triangles it can hit at all. Every
 // lane walks its own list (lanes of a wave look in different cells), records come through per-lane vector loads; the
 // index of the next entry is fetched while the current triangle is tested. Same exact test, explicit lowest-index rule.
 // `gn` <- the accepted triangle's geometric normal, which travels in its record.
-__device__ __forceinline__ Hit intersect_grid(const PtKernelParams& p, v3 rd, unsigned& tests, v3& gn, bool use_occ) {
-    Hit h;
-    h.t = 1.0e38f; h.id = -1; h.u = 0.f; h.v = 0.f; h.ood = 0.f;
+// `want`: lanes without a query pass false and get "nothing hit" (callers inside a branch pass true).
+__device__ __forceinline__ Hit intersect_grid(const PtKernelParams& p, v3 rd, bool want, unsigned& tests, v3& gn, bool use_occ) {
+    // (One exit, and the hit record is touched by the list loop only: with early returns the compiler set the record's
+    // registers to "nothing hit" again at every one of them, four times per query.)
     const float ax = __builtin_fabsf(rd.x), ay = __builtin_fabsf(rd.y), az = __builtin_fabsf(rd.z);
     // major axis by selects (no branches: the three cases are spread evenly over the lanes of a wave)
     const bool xmaj = ax >= ay && ax >= az, ymaj = !xmaj && ay >= az;
@@ -602,41 +609,54 @@ __device__ __forceinline__ Hit intersect_grid(const PtKernelParams& p, v3 rd, un
     const float fv = xmaj ? rd.z : (ymaj ? rd.x : rd.y);
     const float fw = __builtin_fabsf(major);
     const int face = (xmaj ? 0 : (ymaj ? 2 : 4)) + (major < 0.f ? 1 : 0);
-    if (!(fw > 0.f)) return h;  // a zero or NaN direction hits nothing
-    const float iw = __builtin_amdgcn_rcpf(fw);
-    const int res = p.grid_res;
-    const float half = 0.5f * (float)res;
-    int iu = (int)__builtin_floorf((fu * iw + 1.0f) * half), iv = (int)__builtin_floorf((fv * iw + 1.0f) * half);
-    // clamp to [0, res - 1] (res >= 1): the median of the three, one instruction each
-    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(iu) : "v"(iu), "s"(res - 1));
-    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(iv) : "v"(iv), "s"(res - 1));
-    // < 6 * 2048^2; both factors of either product are below 2^24, so the full-rate 24-bit multiply is exact
-    const uint32_t cell = __umul24(__umul24((uint32_t)face, (uint32_t)res) + (uint32_t)iv, (uint32_t)res) + (uint32_t)iu;
-    // Open scenes: one bit per 4x4 block of cells says whether anything lies that way at all (read from a table small enough to
-    // stay next to the compute units; the cell word of a fine grid comes from the fabric).
-    if (use_occ) {  // (wave-uniform)
-        const uint32_t edge = (uint32_t)PT_GRID_OCC_EDGE(res);
-        const uint32_t blk = __umul24(__umul24((uint32_t)face, edge) + ((uint32_t)iv >> 2), edge) + ((uint32_t)iu >> 2);
-        if (!((p.grid_occ[blk >> 5] >> (blk & 31u)) & 1u)) return h;
-    }
     // One word per cell: empty, the cell's only triangle (then the record is the very next fetch), or the position of its
     // list, whose last entry carries the top bit.
-    uint32_t entry = p.grid_cells[cell];
-    if (entry == PT_GRID_EMPTY) return h;
-    const float4* __restrict__ recs = reinterpret_cast<const float4*>(p.grid_tris);
-    uint32_t pos = 0u;
-    if (entry & 0x80000000u) {
-        pos = entry & 0x7fffffffu;
-        entry = p.grid_list[pos];
-    } else {
-        entry |= 0x80000000u;
+    uint32_t entry = PT_GRID_EMPTY;
+    if (want && fw > 0.f) {  // a zero or NaN direction hits nothing
+        const float iw = __builtin_amdgcn_rcpf(fw);
+        const int res = p.grid_res;
+        const float half = 0.5f * (float)res;
+        int iu = (int)__builtin_floorf((fu * iw + 1.0f) * half), iv = (int)__builtin_floorf((fv * iw + 1.0f) * half);
+        // clamp to [0, res - 1] (res >= 1): the median of the three, one instruction each
+        asm("v_med3_i32 %0, %1, 0, %2" : "=v"(iu) : "v"(iu), "s"(res - 1));
+        asm("v_med3_i32 %0, %1, 0, %2" : "=v"(iv) : "v"(iv), "s"(res - 1));
+        // < 6 * 2048^2; both factors of either product are below 2^24, so the full-rate 24-bit multiply is exact
+        const uint32_t cell = __umul24(__umul24((uint32_t)face, (uint32_t)res) + (uint32_t)iv, (uint32_t)res) + (uint32_t)iu;
+        // Open scenes: one bit per 4x4 block of cells says whether anything lies that way at all (read from a table small enough
+        // to stay next to the compute units; the cell word of a fine grid comes from the fabric).
+        bool look = true;
+        if (use_occ) {  // (wave-uniform)
+            const uint32_t edge = (uint32_t)PT_GRID_OCC_EDGE(res);
+            const uint32_t blk = __umul24(__umul24((uint32_t)face, edge) + ((uint32_t)iv >> 2), edge) + ((uint32_t)iu >> 2);
+            look = ((p.grid_occ[blk >> 5] >> (blk & 31u)) & 1u) != 0u;
+        }
+        if (look) entry = grid_word(p.grid_cells, cell);
     }
-    for (;;) {
+    bool more = entry != PT_GRID_EMPTY;
+    uint32_t pos = 0u;
+    if (more) {
+        if (entry & 0x80000000u) {
+            pos = entry & 0x7fffffffu;
+            entry = grid_word(p.grid_list, pos);
+        } else {
+            entry |= 0x80000000u;
+        }
+    }
+    // "Nothing hit" is distance 1e38 and index -1, set once here (the empty statement keeps the compiler from setting the two
+    // again on every path around the loop). The other three words and `gn` are read by callers only after a hit has written
+    // them: they start as whatever their registers hold.
+    Hit h;
+    h.t = 1.0e38f; h.id = -1;
+    asm volatile("" : "+v"(h.t), "+v"(h.id));
+    asm volatile("" : "=v"(h.u), "=v"(h.v), "=v"(h.ood));
+    while (more) {
         const uint32_t tri = entry & 0x7fffffffu;
         const bool last = (entry & 0x80000000u) != 0u;
-        if (!last) entry = p.grid_list[++pos];  // fetched while this triangle is tested
+        if (!last) entry = grid_word(p.grid_list, ++pos);  // fetched while this triangle is tested
+        // (byte offset in 32 bits, see grid_word: pt_capi.hip keeps direction grids to meshes of at most 2^26 triangles)
+        const float4* __restrict__ rec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.grid_tris) + (tri << 6));
         TriRec t;
-        t.a = recs[4 * (size_t)tri]; t.b = recs[4 * (size_t)tri + 1]; t.c = recs[4 * (size_t)tri + 2]; t.d = recs[4 * (size_t)tri + 3];
+        t.a = rec[0]; t.b = rec[1]; t.c = rec[2]; t.d = rec[3];
         const v3 e1 = V(t.a.x, t.a.y, t.a.z);
         const v3 e2 = V(t.a.w, t.b.x, t.b.y);
         const v3 q = cross3(rd, e2);
@@ -657,7 +677,7 @@ __device__ __forceinline__ Hit intersect_grid(const PtKernelParams& p, v3 rd, un
             }
         }
         ++tests;
-        if (last) break;
+        more = !last;
     }
     return h;
 }
@@ -866,8 +886,14 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
         Hit h;
         h.id = -1; h.t = 1.0e38f; h.u = h.v = h.ood = 0.f;
         v3 n = V(0.f, 0.f, 0.f);
+#ifdef PT_V_COUNT_ITERS
+        const unsigned tests_before = lane_tests;
+#endif
         if (KIND == 3) {
             h = intersect_mesh_culled(p, d, want, cull0, tri_tests);
+        } else if (KIND == 4) {
+            n = n_out;  // (kept when nothing is hit: no register to clear, and the caller reads the normal only after a hit)
+            h = intersect_grid(p, d, want, lane_tests, n, use_occ);
         } else if (want) {
             if (KIND == 0) h = intersect_world(p.spheres, o, d, n);
             else if (KIND == 1) h = MATERIALS ? intersect_mesh_from(p.tris_abs, p.num_triangles, o, d, loop_full) : intersect_mesh(p.tris, live_triangles(p), d, loop_full);
@@ -877,8 +903,16 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
                 h = intersect_bvh_lanes(p, o, d, s_lane_stack[threadIdx.x >> 6], overflow, lane_tests);
                 if (overflow) h = intersect_bvh<true>(p, o, d, s_stack[threadIdx.x >> 6], node_visits, tri_tests);
             }
-            else h = intersect_grid(p, d, lane_tests, n, use_occ);
         }
+#ifdef PT_V_COUNT_ITERS
+        // measurement variant, direction grid: trips of the list loop as the WAVE ran them (the longest list among its lanes)
+        // -> node_visits; wave queries in which more than one lane had something to test -> tri_tests
+        if (KIND == 4) {
+            const unsigned mine = want ? lane_tests - tests_before : 0u;
+            node_visits += __builtin_amdgcn_readfirstlane(__reduce_max_trips(mine));
+            tri_tests += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(mine > 1u));
+        }
+#endif
         const bool hit = want && h.id >= 0;
         if (hit && KIND != 0 && !(KIND == 4 && p.normal_mode != 0)) n = mesh_normal(p, h);  // (the grid's records hold the geometric normal)
         n_out = n; t_out = h.t; id_out = h.id;
@@ -1036,6 +1070,12 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
             if (KIND == 4 || KIND == 5) cost = 8u * wave_trips + (unsigned)(wave_tests >> 4);
             atomicAdd(&p.tile_cost[tile], cost);
         }
+#ifdef PT_V_COUNT_ITERS
+        if (KIND == 4) {
+            atomicAdd(&counters[2], (unsigned long long)__builtin_amdgcn_readfirstlane(node_visits));
+            atomicAdd(&counters[3], (unsigned long long)__builtin_amdgcn_readfirstlane(tri_tests));
+        }
+#endif
         if (KIND == 2 || KIND == 3 || KIND == 5) {  // 5: what the per-wave walk did for lanes whose own stack was full
             atomicAdd(&counters[2], (unsigned long long)__builtin_amdgcn_readfirstlane(node_visits));
             atomicAdd(&counters[3], (unsigned long long)__builtin_amdgcn_readfirstlane(tri_tests));
@@ -1324,7 +1364,7 @@ __global__ __launch_bounds__(64, PT_DECOUPLED_MIN_WAVES) void pt_render_decouple
         if (state == WALK) {
             unsigned grid_tests = 0;
             v3 gn;
-            w.h = intersect_grid(p, rd, grid_tests, gn, p.grid_occ != nullptr);
+            w.h = intersect_grid(p, rd, true, grid_tests, gn, p.grid_occ != nullptr);
             walk_over();
         }
     }
@@ -1614,7 +1654,7 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_primary_kernel(const PtKer
     if (KIND == 1) h = intersect_mesh(p.tris, live_triangles(p), rd, tt);
     if (KIND == 2) h = intersect_bvh<false>(p, ro, rd, s_stack[threadIdx.x >> 6], nv, tt);
     if (KIND == 3) h = intersect_mesh_culled(p, rd, in_window, load_cull(reinterpret_cast<const float4*>(p.cull), threadIdx.x & 63, p.num_triangles), tt);
-    if (KIND == 4) h = intersect_grid(p, rd, tt, N, p.grid_occ != nullptr);
+    if (KIND == 4) h = intersect_grid(p, rd, true, tt, N, p.grid_occ != nullptr);
     if (!in_window) return;
     if (p.out_ids) p.out_ids[pix] = h.id;
     if (p.out_t) p.out_t[pix] = h.t;
@@ -1659,7 +1699,7 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_verify_kernel(const PtKern
                 do { r = walk_round(p, w, ro, rd, my, true, nv, tt); } while (r == 0);
                 b = w.h;
                 if (r == 2) b = intersect_bvh<true>(p, ro, rd, s_stack[threadIdx.x >> 6], nv, tt);
-            } else b = intersect_grid(p, rd, tt, gn, p.grid_occ != nullptr);  // (the block bits are checked whenever they exist)
+            } else b = intersect_grid(p, rd, true, tt, gn, p.grid_occ != nullptr);  // (the block bits are checked whenever they exist)
             ++compared;
             bad_id += a.id != b.id ? 1u : 0u;
             bad_t += __float_as_uint(a.t) != __float_as_uint(b.t) ? 1u : 0u;

@@ -23,6 +23,7 @@ VARIANTS = {
     "memclause": ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"],
     "nounroll": ["-fno-unroll-loops"],
     "o2": ["-O2"],
+    "iters": ["-DPT_V_COUNT_ITERS"],   # direction grid: list-loop trips per wave in bvh_node_fetches, lanes with >1 test in bvh_triangle_fetches
 }
 
 
@@ -92,12 +93,14 @@ def main():
             t.finish()
             st = t.stats()
             times[v].append(st["last_dispatch_ms"])
-            util[v] = (st["rays"], st["rays"] / max(1, st["lane_slots"]))
+            util[v] = (st["rays"], st["rays_traced"] / max(1, st["lane_slots"]))
     for v in names:
         rays, u = util[v]
         ms = statistics.median(times[v])
         print(json.dumps({"variant": v, "median_ms": round(ms, 3), "min_ms": round(min(times[v]), 3),
                           "Grays_per_s": round(rays / ms * 1e-6, 2), "lane_utilisation": round(u, 4), "tri_records_per_wave_ray": round(st["bvh_triangle_fetches"] * 64 / max(1, st["lane_slots"]), 2),
+                          "node_records_per_wave_ray": round(st["bvh_node_fetches"] * 64 / max(1, st["lane_slots"]), 3),
+                          "grid_tests_per_traced_ray": round(st["grid_triangle_tests"] / max(1, st["rays_traced"]), 3),
                           "same_image_as_first": tracers[v][1]}))
 
 
