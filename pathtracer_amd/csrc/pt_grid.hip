@@ -20,14 +20,19 @@ namespace {
 
 struct P3 { float x, y, z; };
 
-// face f = 2 * axis + (negative ? 1 : 0); local coordinates (u, v, w) with w > 0 inside the face's pyramid
+// face f = 2 * axis + (negative ? 1 : 0); local coordinates (u, v, w) with w > 0 inside the face's pyramid. (u, v) are the
+// cube-map coordinates (sc, tc) the hardware's cube instructions give a direction of that face, which is what a query uses
+// (cube_coords in pt_kernels.hip): +x: (-z, -y), -x: (z, -y), +y: (x, z), -y: (x, -z), +z: (x, -y), -z: (-x, -y).
 __device__ __forceinline__ P3 to_face(P3 p, int f) {
-    const int axis = f >> 1;
-    const float s = (f & 1) ? -1.0f : 1.0f;
     P3 q;
-    if (axis == 0) { q.x = p.y; q.y = p.z; q.z = s * p.x; }
-    else if (axis == 1) { q.x = p.z; q.y = p.x; q.z = s * p.y; }
-    else { q.x = p.x; q.y = p.y; q.z = s * p.z; }
+    switch (f) {
+        case 0: q.x = -p.z; q.y = -p.y; q.z = p.x; break;
+        case 1: q.x = p.z; q.y = -p.y; q.z = -p.x; break;
+        case 2: q.x = p.x; q.y = p.z; q.z = p.y; break;
+        case 3: q.x = p.x; q.y = -p.z; q.z = -p.y; break;
+        case 4: q.x = p.x; q.y = -p.y; q.z = p.z; break;
+        default: q.x = -p.x; q.y = -p.y; q.z = -p.z; break;
+    }
     return q;
 }
 

@@ -587,6 +587,27 @@ __device__ __forceinline__ Hit intersect_bvh_lanes(const PtKernelParams& p, v3 r
     }
 }
 
+// The cube-map face of a direction, by the hardware's cube instructions: id = face number 0..5 (+x, -x, +y, -y, +z, -z: the
+// component of largest magnitude and its sign), ma = twice that component, (sc, tc) = the other two with the signs of the
+// cube-map convention. cube_coords_expected() states the selections in C++; pt_arith_selftest_kernel compares the two.
+struct CubeCoords { float id, sc, tc, ma; };
+__device__ __forceinline__ CubeCoords cube_coords(v3 d) {
+    CubeCoords c;
+    c.id = __builtin_amdgcn_cubeid(d.x, d.y, d.z);
+    c.sc = __builtin_amdgcn_cubesc(d.x, d.y, d.z);
+    c.tc = __builtin_amdgcn_cubetc(d.x, d.y, d.z);
+    c.ma = __builtin_amdgcn_cubema(d.x, d.y, d.z);
+    return c;
+}
+__device__ __forceinline__ CubeCoords cube_coords_expected(v3 d) {
+    const float ax = __builtin_fabsf(d.x), ay = __builtin_fabsf(d.y), az = __builtin_fabsf(d.z);
+    CubeCoords c;
+    if (az >= ax && az >= ay) { c.id = d.z < 0.f ? 5.f : 4.f; c.sc = d.z < 0.f ? -d.x : d.x; c.tc = -d.y; c.ma = 2.0f * d.z; }
+    else if (ay >= ax)        { c.id = d.y < 0.f ? 3.f : 2.f; c.sc = d.x; c.tc = d.y < 0.f ? -d.z : d.z; c.ma = 2.0f * d.y; }
+    else                      { c.id = d.x < 0.f ? 1.f : 0.f; c.sc = d.x < 0.f ? d.z : -d.z; c.tc = -d.y; c.ma = 2.0f * d.x; }
+    return c;
+}
+
 // A word of one of the direction grid's tables. The byte offset is formed in 32 bits and added to the (wave-uniform) base by
 // the load itself: the tables stay below 4 GiB (6 * 2048^2 cell words; at most 2^30 list words).
 __device__ __forceinline__ uint32_t grid_word(const uint32_t* __restrict__ table, uint32_t index) {
@@ -601,33 +622,32 @@ __device__ __forceinline__ uint32_t grid_word(const uint32_t* __restrict__ table
 __device__ __forceinline__ Hit intersect_grid(const PtKernelParams& p, v3 rd, bool want, unsigned& tests, v3& gn, bool use_occ) {
     // (One exit, and the hit record is touched by the list loop only: with early returns the compiler set the record's
     // registers to "nothing hit" again at every one of them, four times per query.)
-    const float ax = __builtin_fabsf(rd.x), ay = __builtin_fabsf(rd.y), az = __builtin_fabsf(rd.z);
-    // major axis by selects (no branches: the three cases are spread evenly over the lanes of a wave)
-    const bool xmaj = ax >= ay && ax >= az, ymaj = !xmaj && ay >= az;
-    const float major = xmaj ? rd.x : (ymaj ? rd.y : rd.z);
-    const float fu = xmaj ? rd.y : (ymaj ? rd.z : rd.x);
-    const float fv = xmaj ? rd.z : (ymaj ? rd.x : rd.y);
-    const float fw = __builtin_fabsf(major);
-    const int face = (xmaj ? 0 : (ymaj ? 2 : 4)) + (major < 0.f ? 1 : 0);
+    // Face and face coordinates from the cube-map instructions (exact selections and sign changes, no rounding): `id` = 2 * axis +
+    // (negative ? 1 : 0), `ma` = twice the major component, (sc, tc) = the other two components in the orientation that
+    // pt_grid.hip's to_face() lists per face. Which face a tie between two magnitudes goes to does not matter: the build widens
+    // every face's pyramid.
+    const CubeCoords cc = cube_coords(rd);
+    const float fw2 = __builtin_fabsf(cc.ma);
     // One word per cell: empty, the cell's only triangle (then the record is the very next fetch), or the position of its
     // list, whose last entry carries the top bit.
     uint32_t entry = PT_GRID_EMPTY;
-    if (want && fw > 0.f) {  // a zero or NaN direction hits nothing
-        const float iw = __builtin_amdgcn_rcpf(fw);
+    if (want && fw2 > 0.f) {  // a zero or NaN direction hits nothing
+        const float iw2 = __builtin_amdgcn_rcpf(fw2);  // 1 / (2 |major|): sc * iw2 lies in [-0.5, 0.5]
         const int res = p.grid_res;
-        const float half = 0.5f * (float)res;
-        int iu = (int)__builtin_floorf((fu * iw + 1.0f) * half), iv = (int)__builtin_floorf((fv * iw + 1.0f) * half);
+        const float fres = (float)res;
+        const uint32_t face = (uint32_t)cc.id;
+        int iu = (int)__builtin_floorf((cc.sc * iw2 + 0.5f) * fres), iv = (int)__builtin_floorf((cc.tc * iw2 + 0.5f) * fres);
         // clamp to [0, res - 1] (res >= 1): the median of the three, one instruction each
         asm("v_med3_i32 %0, %1, 0, %2" : "=v"(iu) : "v"(iu), "s"(res - 1));
         asm("v_med3_i32 %0, %1, 0, %2" : "=v"(iv) : "v"(iv), "s"(res - 1));
         // < 6 * 2048^2; both factors of either product are below 2^24, so the full-rate 24-bit multiply is exact
-        const uint32_t cell = __umul24(__umul24((uint32_t)face, (uint32_t)res) + (uint32_t)iv, (uint32_t)res) + (uint32_t)iu;
+        const uint32_t cell = __umul24(__umul24(face, (uint32_t)res) + (uint32_t)iv, (uint32_t)res) + (uint32_t)iu;
         // Open scenes: one bit per 4x4 block of cells says whether anything lies that way at all (read from a table small enough
         // to stay next to the compute units; the cell word of a fine grid comes from the fabric).
         bool look = true;
         if (use_occ) {  // (wave-uniform)
             const uint32_t edge = (uint32_t)PT_GRID_OCC_EDGE(res);
-            const uint32_t blk = __umul24(__umul24((uint32_t)face, edge) + ((uint32_t)iv >> 2), edge) + ((uint32_t)iu >> 2);
+            const uint32_t blk = __umul24(__umul24(face, edge) + ((uint32_t)iv >> 2), edge) + ((uint32_t)iu >> 2);
             look = ((p.grid_occ[blk >> 5] >> (blk & 31u)) & 1u) != 0u;
         }
         if (look) entry = grid_word(p.grid_cells, cell);
@@ -1728,7 +1748,7 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_verify_kernel(const PtKern
 
 // The short reciprocal, square-root and log2-quotient sequences against the compiler's IEEE division and square root, for
 // every float bit pattern: bad[0] reciprocal, bad[1] square root, bad[2] quotient and the restricted-domain forms (rand01's
-// tail, pow of a value in [0, 1), exp2 without clamps) -- inputs whose results differ in any bit (NaN payloads included). All
+// tail, pow of a value in [0, 1), exp2 without clamps) and the cube-map instructions against their definition -- inputs whose results differ in any bit (NaN payloads included). All
 // three must stay 0.
 __global__ __launch_bounds__(256) void pt_arith_selftest_kernel(unsigned long long* __restrict__ bad) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -1749,6 +1769,23 @@ __global__ __launch_bounds__(256) void pt_arith_selftest_kernel(unsigned long lo
         if (x != x || (x >= 0.0f && x < 1.0f)) {
             b2 += __float_as_uint(lp_pow_unit(x, 1.0f / 1025.0f)) != __float_as_uint(lp_pow(x, 1.0f / 1025.0f));
             b2 += __float_as_uint(lp_pow_unit(x, 0.5f)) != __float_as_uint(lp_pow(x, 0.5f));
+        }
+        // the cube-map instructions against the selections written out, on directions made of this bit pattern, of two
+        // scrambled ones and of their ties (equal magnitudes, zeros),
+        {
+            const float y = __uint_as_float((uint32_t)i * 2654435761u), z = __uint_as_float(((uint32_t)i ^ 0x5bd1e995u) * 2246822519u);
+            const v3 dirs[4] = {V(x, y, z), V(x, -x, y), V(y, x, x), V(x, 0.0f, -x)};
+            for (int k = 0; k < 4; ++k) {
+                const CubeCoords a = cube_coords(dirs[k]), e = cube_coords_expected(dirs[k]);
+                // (left out: NaN and infinite components, denormal ones -- flushed by the arithmetic here, not by a selection --
+                // and the all-zero vector, whose face is the sign of a zero: none of them is a direction that can hit anything,
+                // and a query with a zero or NaN major component looks nothing up)
+                auto odd = [](float c) { const uint32_t b = __float_as_uint(c) & 0x7fffffffu; return b >= 0x7f800000u || (b != 0u && b < 0x00800000u); };
+                const bool zero = dirs[k].x == 0.0f && dirs[k].y == 0.0f && dirs[k].z == 0.0f;
+                if (!zero && !odd(dirs[k].x) && !odd(dirs[k].y) && !odd(dirs[k].z))
+                    b2 += __float_as_uint(a.id) != __float_as_uint(e.id) || __float_as_uint(a.sc) != __float_as_uint(e.sc) ||
+                          __float_as_uint(a.tc) != __float_as_uint(e.tc) || __float_as_uint(a.ma) != __float_as_uint(e.ma);
+            }
         }
         // and exp2 without its clamps over the exponents of the Fresnel term: -8.656170 * c for every c in [0, 1]
         if (x >= 0.0f && x <= 1.0f) {
