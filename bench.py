@@ -44,19 +44,19 @@ FLOP_PER_TRI_TEST_SHADER = 43
 # integer and address arithmetic are not counted, and a division or square root counts as ONE although it issues 4-9
 # instructions). Events come from the kernel's own counters (PtStats).
 FLOP = {
-    "rand01": 15,           # Rng::rand01: 4 add, 3 (2 mul + add), 2 fract (floor + sub), 1 mul, add, floor + sub
+    "rand01": 13,           # Rng::rand01: 4 add, 3 (2 mul + add), 2 fract (floor + sub), 1 mul, add (the shader's final mod(r, 1.0) is the identity on its argument and is not executed)
     "normalize": 10,        # dot3 (3 mul + 2 add), sqrt, reciprocal, 3 mul
     "cross": 9,
     "reflect": 12,          # dot3, 2*, 3 mul, 3 sub
-    "pow": 42,              # lp_log2 25 (quotient 12, polynomial 13) + mul + lp_exp2 16
+    "pow": 41,              # lp_log2 25 (quotient 12, polynomial 13) + mul + lp_exp2 15 (lower clamp only: the argument is <= 0)
     "sincos_pair": 32,      # lp_sincos<true> and <false> of one angle: shared reduction and both polynomials 28, two selections 4
-    "exp2": 16,
-    # shade(): reflect 12, two rand01 30, tangent frame 2 x (cross 9 + normalize 10) 38, pow 42, sin_t 4, phi 2, sincos 32,
-    # hemi 2, new direction 15, dot(N, rd) 5, clamps 4, Fresnel exp2 16 + 4, specular 3, throughput 2  -> 211
-    "shade_reference": 211,
-    # shade_materials(), Lambert branch: hit point 6, two rand01 30, tangent frame 38, pow 42, sin_t 4, phi 2, sincos 32, hemi 2,
-    # new direction 15, new origin 6, throughput 3 -> 180 (the emitter branch is 6)
-    "shade_materials": 180,
+    "exp2": 14,             # without clamps (the Fresnel exponent lies in [-8.66, 0])
+    # shade(): reflect 12, two rand01 26, tangent frame 2 x (cross 9 + normalize 10) 38, pow 41, sin_t 4, phi 2, sincos 32,
+    # hemi 2, new direction 15, dot(N, rd) 5, clamps 4, Fresnel exp2 14 + 4, specular 3, throughput 2  -> 204
+    "shade_reference": 204,
+    # shade_materials(), Lambert branch: hit point 6, two rand01 26, tangent frame 38, pow 41, sin_t 4, phi 2, sincos 32, hemi 2,
+    # new direction 15, new origin 6, throughput 3 -> 175 (the emitter branch is 6)
+    "shade_materials": 175,
     "vertex_normal": 29,    # mesh_normal(): barycentrics 4, blend 15, normalize 10 (not for geometric normals)
     "sample_end": 21,       # sky 12 (fs:408-410), running mean 9 (fs:414)
     "grid_query": 9,        # reciprocal of the major axis, 2 x (mul, add, mul, floor)
