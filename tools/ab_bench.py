@@ -23,6 +23,7 @@ VARIANTS = {
     "memclause": ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"],
     "nounroll": ["-fno-unroll-loops"],
     "o2": ["-O2"],
+    "countfull": ["-DPT_V_COUNT_FULL"],  # all-triangles loops: counts the tests past the wave-uniform back-face skip (tools/pmc_collect.py uses it)
     "iters": ["-DPT_V_COUNT_ITERS"],   # direction grid: list-loop trips per wave in bvh_node_fetches, lanes with >1 test in bvh_triangle_fetches
 }
 

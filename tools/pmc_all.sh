@@ -1,4 +1,5 @@
 # The tracked counter profiles of the round: one tools/pmc_collect.py run per kernel family (on the GPU box).
+# Before sending the tree: python3 tools/ab_bench.py --build --only countfull   (the counting build the loop kernels' entries need)
 set -e
 cd $GRAFT_REPO_ROOT
 run() { tag=$1; shift; timeout -k 10 500 python3 tools/pmc_collect.py $tag "$@" > gpurun_out/pmc_$tag.log 2>&1 || { tail -20 gpurun_out/pmc_$tag.log; exit 1; }; tail -3 gpurun_out/pmc_$tag.log; }
