@@ -74,7 +74,8 @@ typedef enum PtAccelMode {
     PT_ACCEL_GRID = 4,  /* require the direction grid (built by pt_build_accel, rebuilt when the camera position changes): the
                            shader never moves its ray origin, so every query is "what does the camera position see in this
                            direction"; directions are binned into cube-map cells that list the triangles they can hit.
-                           Reference shading only (PT_SHADE_MATERIALS moves the origin) */
+                           Reference shading only (PT_SHADE_MATERIALS moves the origin), meshes of at most 2^26 triangles
+                           (pt_dispatch returns PT_ERR_INVALID_ARGUMENT beyond; PT_ACCEL_AUTO then walks the hierarchy) */
     PT_ACCEL_CULL = 3   /* all-triangles loop that skips, 64 triangles at a time, those no ray of the wave can reach;
                            exact, but measured slower than BRUTE (36 triangles) and BVH (>= 64): kept for experiments */
 } PtAccelMode;
