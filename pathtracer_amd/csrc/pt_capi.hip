@@ -544,7 +544,8 @@ PtStatus fill_params(PtContext* ctx, PtKernelParams* p, const Program** prog_out
         // may not allocate uses the grid only if an earlier dispatch of this camera position built it.
         bool grid_for_camera_rays = false;
         if (is_materials(ctx->shading_mode) && use_bvh && ctx->lane_walk == 1 && ctx->primary_reuse && ctx->grid_wanted && ctx->auto_grid &&
-            ctx->accel_mode == PT_ACCEL_AUTO && ctx->camera_ray_grid && u.depth > 0 && (ctx->grid_valid || (ctx->dispatches_here >= 1 && !ctx->no_alloc))) {
+            ctx->accel_mode == PT_ACCEL_AUTO && ctx->camera_ray_grid && u.depth > 0 && u.num_triangles <= (1 << 26) &&
+            (ctx->grid_valid || (ctx->dispatches_here >= 1 && !ctx->no_alloc))) {
             PtStatus gs = ensure_grid(ctx);
             if (gs != PT_OK) return gs;
             grid_for_camera_rays = ctx->grid_built;
@@ -782,6 +783,7 @@ PtStatus pt_upload_materials(PtContext* ctx, const float* rgbt, int32_t count) {
     PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (ctx->d_materials) (void)hipFree(ctx->d_materials);
     ctx->d_materials = nullptr;
+    ctx->num_materials = 0;
     PT_HIP_TRY(hipMalloc(&ctx->d_materials, (size_t)count * 4 * sizeof(float)));
     PT_HIP_TRY(hipMemcpyAsync(ctx->d_materials, rgbt, (size_t)count * 4 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -803,21 +805,31 @@ PtStatus pt_upload_mesh(PtContext* ctx, const float* vertices, int32_t num_verti
     PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
     free_mesh(ctx);
     const size_t nt = (size_t)num_triangles;
-    PT_HIP_TRY(hipMalloc(&ctx->d_vertices, (size_t)num_vertices * 6 * sizeof(float)));
-    PT_HIP_TRY(hipMalloc(&ctx->d_indices, nt * 3 * sizeof(uint32_t)));
-    PT_HIP_TRY(hipMalloc(&ctx->d_tris, (nt + PT_TRI_PAD) * PT_TRI_FLOATS * sizeof(float)));
-    PT_HIP_TRY(hipMemsetAsync(ctx->d_tris + nt * PT_TRI_FLOATS, 0, PT_TRI_PAD * PT_TRI_FLOATS * sizeof(float), ctx->stream));
-    PT_HIP_TRY(hipMalloc(&ctx->d_tris_live, (nt + PT_TRI_PAD) * PT_TRI_FLOATS * sizeof(float)));
-    PT_HIP_TRY(hipMalloc(&ctx->d_live_count, sizeof(uint32_t)));
-    PT_HIP_TRY(hipMalloc(&ctx->d_vnormals, nt * 9 * sizeof(float)));
-    PT_HIP_TRY(hipMalloc(&ctx->d_gnormals, nt * 3 * sizeof(float)));
-    PT_HIP_TRY(hipMalloc(&ctx->d_cull, nt * PT_CULL_FLOATS * sizeof(float)));
-    PT_HIP_TRY(hipMalloc(&ctx->d_tris_abs, (nt + PT_TRI_PAD) * PT_TRI_FLOATS * sizeof(float)));
-    PT_HIP_TRY(hipMalloc(&ctx->d_tris_grid, nt * PT_TRI_FLOATS * sizeof(float)));
-    PT_HIP_TRY(hipMemsetAsync(ctx->d_tris_abs + nt * PT_TRI_FLOATS, 0, PT_TRI_PAD * PT_TRI_FLOATS * sizeof(float), ctx->stream));
-    PT_HIP_TRY(hipMemcpyAsync(ctx->d_vertices, vertices, (size_t)num_vertices * 6 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    PT_HIP_TRY(hipMemcpyAsync(ctx->d_indices, indices, nt * 3 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    // (one error variable and one clean-up: a failure half-way leaves no mesh, not a half-allocated one)
+    hipError_t e = hipSuccess;
+    auto alloc = [&e](auto** ptr, size_t bytes) {
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(ptr), bytes);
+    };
+    alloc(&ctx->d_vertices, (size_t)num_vertices * 6 * sizeof(float));
+    alloc(&ctx->d_indices, nt * 3 * sizeof(uint32_t));
+    alloc(&ctx->d_tris, (nt + PT_TRI_PAD) * PT_TRI_FLOATS * sizeof(float));
+    alloc(&ctx->d_tris_live, (nt + PT_TRI_PAD) * PT_TRI_FLOATS * sizeof(float));
+    alloc(&ctx->d_live_count, sizeof(uint32_t));
+    alloc(&ctx->d_vnormals, nt * 9 * sizeof(float));
+    alloc(&ctx->d_gnormals, nt * 3 * sizeof(float));
+    alloc(&ctx->d_cull, nt * PT_CULL_FLOATS * sizeof(float));
+    alloc(&ctx->d_tris_abs, (nt + PT_TRI_PAD) * PT_TRI_FLOATS * sizeof(float));
+    alloc(&ctx->d_tris_grid, nt * PT_TRI_FLOATS * sizeof(float));
+    if (e == hipSuccess) e = hipMemsetAsync(ctx->d_tris + nt * PT_TRI_FLOATS, 0, PT_TRI_PAD * PT_TRI_FLOATS * sizeof(float), ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(ctx->d_tris_abs + nt * PT_TRI_FLOATS, 0, PT_TRI_PAD * PT_TRI_FLOATS * sizeof(float), ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_vertices, vertices, (size_t)num_vertices * 6 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_indices, indices, nt * 3 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(ctx->stream);
+        free_mesh(ctx);
+        return fail(PT_ERR_HIP, "mesh upload failed (%d vertices, %d triangles): %s", num_vertices, num_triangles, hipGetErrorString(e));
+    }
     ctx->num_vertices = num_vertices;
     ctx->num_triangles = num_triangles;
     ctx->records_valid = false;
