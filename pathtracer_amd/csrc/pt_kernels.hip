@@ -888,8 +888,11 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
 
     int remaining = in_window ? sample_count : 0;
     int sample = p.first_sample + sample_begin * p.sample_stride;
-    unsigned rays = 0;    // closest-hit queries in the reference's sense: one per bounce-loop iteration (PathTracer.cpp:947)
+    // Closest-hit queries in the reference's sense (one per bounce-loop iteration, PathTracer.cpp:947) are not counted one by
+    // one: they are the queries this lane evaluated plus the camera-ray queries answered by a reused result, one per sample
+    // from the second on (and the first too when it came from an earlier dispatch) -- formed once, after the loop.
     unsigned traced = 0;  // queries this lane actually evaluated
+    bool first_from_cache = false;
     unsigned trips = 0;   // queries evaluated by the WAVE: trips x 64 lane slots were spent for `traced` useful ones
     unsigned node_visits = 0, tri_tests = 0;  // per WAVE (the BVH walk is wave-uniform): records fetched
     unsigned lane_tests = 0;                  // per LANE (direction grid): triangles tested
@@ -957,12 +960,12 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
                 N0 = V(c.x, c.y, c.z);
                 id0 = (int)__float_as_uint(c.w);
                 hit0 = id0 >= 0;
-                ++rays;
+                first_from_cache = true;
             }
         } else {
             if (KIND == 3 || want0) hit0 = intersect(ro0, rd0, want0, N0, t0, id0);
             if (__builtin_amdgcn_ballot_w64(want0)) ++trips;
-            if (want0) { ++traced; ++rays; }  // ++rays: the first sample's camera-ray query; later samples count theirs when they start
+            if (want0) ++traced;
             if (!MATERIALS && p.primary_cache && want0) p.primary_cache[pix] = make_float4(N0.x, N0.y, N0.z, __uint_as_float((uint32_t)id0));
         }
     }
@@ -991,7 +994,6 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
             const float t = 0.5f * (rd0.y + 1.0f);
             const float omt = 1.0f - t;
             const float sr = omt + 0.5f * t, sg = omt + 0.7f * t, sb = omt + 1.0f * t;
-            rays += (unsigned)(remaining - 1);  // one camera-ray query per sample; the first is already counted
             for (int k = 0; k < sample_count; ++k) {
                 if (scratch_slot >= 0) {
                     park(&scratch[(size_t)k * PT_TILE_THREADS], sr, sg, sb, 1.0f, rd0.y);
@@ -1039,7 +1041,7 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
         if (KIND == 3 || want) pend_hit = intersect(ro, rd, want, pend_n, pend_t, pend_id);
         if (__builtin_amdgcn_ballot_w64(want)) ++trips;
         if (want) {
-            ++traced; ++rays;
+            ++traced;
             pending = true;
             done = !pend_hit;  // a miss ends the sample in this same trip
         }
@@ -1066,13 +1068,14 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
             rng.samples = (float)sample;
             rng.sx = 0.0f;
             pending = reuse; pend_hit = hit0; pend_n = N0; pend_t = t0; pend_id = id0;
-            if (reuse && remaining > 0) ++rays;  // the new sample's camera-ray query, answered by the reused result
         }
     }
     if (in_window && scratch_slot < 0) {
         const float alpha = p.accum_mode == 0 ? 1.0f : prev.w + (float)p.num_samples;
         reinterpret_cast<float4*>(p.dst)[pix] = make_float4(mr, mg, mb, alpha);
     }
+    unsigned rays = traced;
+    if (reuse && in_window && sample_count > 0) rays += (unsigned)(sample_count - 1) + (first_from_cache ? 1u : 0u);
     const unsigned long long wave_rays = wave_sum(rays), wave_traced = wave_sum(traced);
     const unsigned long long wave_tests = (KIND == 4 || KIND == 5) ? wave_sum(lane_tests) : 0ull;
     const unsigned long long wave_shaded = wave_sum(shaded);
