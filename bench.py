@@ -79,7 +79,7 @@ def kernel_source_hash():
     """Identifies the kernels a profile was taken from: sources + build flags."""
     h = hashlib.sha256()
     for rel in ("pathtracer_amd/csrc/pt_kernels.hip", "pathtracer_amd/csrc/pt_internal.h", "pathtracer_amd/csrc/pt_grid.hip",
-                "pathtracer_amd/csrc/pt_bvh.hip"):
+                "pathtracer_amd/csrc/pt_bvh.hip", "pathtracer_amd/csrc/pt_capi.hip"):   # (the last: grid resolution, work list, launch sizes)
         h.update(open(os.path.join(ROOT, rel), "rb").read())
     from pathtracer_amd import build as ptbuild
     h.update(" ".join(ptbuild.DEVICE_FLAGS).encode())

@@ -290,12 +290,15 @@ hipError_t grid_alloc(PtContext* ctx, T** ptr, size_t bytes) {
     return hipMalloc(reinterpret_cast<void**>(ptr), bytes);
 }
 
-// Cube-map resolution per face: about sixteen cells per triangle over the sphere, within [512, 2048]
+// Cube-map resolution per face, within [768, 2048]
 int grid_resolution(const PtContext* ctx) {
     if (ctx->grid_res_override > 0) return ctx->grid_res_override;
-    // Measured: finer cells keep paying (fewer triangle tests per query) until the cell table falls out of the caches:
-    // 512 is best from 36 to a few thousand triangles, 2048 for a million.
-    int res = 512;
+    // Measured (ms per 256-spp dispatch at 512 / 768 / 1024 / 1536 cells per face edge, static camera): finer cells keep paying
+    // (fewer triangle tests per query) until the cell table's misses cost more -- 36 triangles in a closed box, where every query
+    // fetches a cell word: 7.33 / 7.23 / 7.36 / 7.36; 3,936 triangles in the open: 1.45 / 1.37 / 1.32 / 1.28; 968 and 64 triangles:
+    // no difference; a million: 2048 (about sixteen cells per triangle over the sphere). A camera move rebuilds the grid, and
+    // that grows with the cell count (0.25 / 0.29 / 0.36 ms for the small meshes), so the small meshes stop at 768 and 1024.
+    int res = ctx->num_triangles >= 2000 ? 1024 : 768;
     while (res < 2048 && (double)6 * res * res < 16.0 * (double)ctx->num_triangles) res *= 2;
     return res;
 }
