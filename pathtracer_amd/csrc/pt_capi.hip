@@ -120,6 +120,13 @@ struct PtContext {
     PtBvhBuilder bvh_builder = PT_BVH_BUILDER_SAH;   // PT_BVH_BUILDER=morton / sah sets a context's initial choice
     // direction grid (optional, rebuilt with the records when the camera position changes)
     PtGridBuild grid{};
+    PtGridBuild grid_spare{};   // the arrays of the other resolution (coarse while the fine grid is in use and the other way round),
+                                // kept so that going back and forth between the two allocates nothing
+    bool grid_want_fine = false;   // this camera position has gathered enough samples for the fine grid to pay (pt_dispatch decides)
+    bool grid_fine_over_move = false;  // set by pt_dispatch around its own update of the records (see ensure_records)
+    double grid_fine_after = 4.0e9;    // pixel-samples at one camera position from which the fine grid is used (PT_GRID_FINE_AFTER=x
+                                       // sets it, for tests and measurements; negative: never)
+    double px_samples_here = 0.0;  // pixel-samples dispatched since the mesh or the camera position last changed
     bool grid_wanted = false;   // pt_build_accel was called for this mesh
     bool grid_built = false;
     int32_t grid_res_override = 0;
@@ -273,12 +280,16 @@ void free_bvh(PtContext* ctx) {
     ctx->bvh_trivial = false;
 }
 
-void free_grid(PtContext* ctx) {
-    PtGridBuild& g = ctx->grid;
+void free_grid_arrays(PtGridBuild& g) {
     void* ptrs[] = {g.cell_count, g.cell_start, g.cells, g.list, g.occ, g.scan_tmp, g.big_jobs, g.big_cells, g.big_count};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     g = PtGridBuild{};
+}
+
+// the grid in use (the spare set of arrays stays)
+void free_grid(PtContext* ctx) {
+    free_grid_arrays(ctx->grid);
     ctx->grid_built = false;
 }
 
@@ -296,11 +307,25 @@ int grid_resolution(const PtContext* ctx) {
     // Measured (ms per 256-spp dispatch at 512 / 768 / 1024 / 1536 cells per face edge, static camera): finer cells keep paying
     // (fewer triangle tests per query) until the cell table's misses cost more -- 36 triangles in a closed box, where every query
     // fetches a cell word: 7.33 / 7.23 / 7.36 / 7.36; 3,936 triangles in the open: 1.45 / 1.37 / 1.32 / 1.28; 968 and 64 triangles:
-    // no difference; a million: 2048 (about sixteen cells per triangle over the sphere). A camera move rebuilds the grid, and
-    // that grows with the cell count (0.25 / 0.29 / 0.36 ms for the small meshes), so the small meshes stop at 768 and 1024.
+    // no difference; 98,400 triangles (25 copies of the 3,936) at 1024 / 1536 / 2048: 0.56 / 0.51 / 0.50, 251,904: 0.83 / 0.73 /
+    // 0.67, 31,488: no difference; a million: 2048, the largest offered. A camera move rebuilds the grid, and that grows with the
+    // cell count (0.25 / 0.29 / 0.36 ms for the small meshes), so the small meshes stop at 768 and 1024; 2048 from about 65,000
+    // triangles on (96 triangles' worth of cells over the sphere).
     int res = ctx->num_triangles >= 2000 ? 1024 : 768;
-    while (res < 2048 && (double)6 * res * res < 16.0 * (double)ctx->num_triangles) res *= 2;
+    while (res < 2048 && (double)6 * res * res < 96.0 * (double)ctx->num_triangles) res *= 2;
     return res;
+}
+
+// Resolution for a view that stays: a finer grid keeps paying on a large mesh (1M triangles at 4K, ms per 64-spp dispatch at
+// 2048 / 3072 / 4096 / 8192: 1.61 / 1.36 / 1.28 / 1.19), but its build grows with the cell count (first frame after a camera
+// move: 1.24 / 2.03 / 3.19 ms at 2048 / 3072 / 4096), and on meshes of 100-500 thousand triangles the gain per sample is a
+// quarter of that. So 4096 serves large meshes only, and only once a camera position has gathered the pixel-samples that repay
+// the longer build (pt_dispatch decides, PtContext::grid_fine_after); a camera that keeps moving stays with 2048.
+constexpr int32_t kFineGridMinTriangles = 750000;   // (PtContext::grid_fine_after: 4e9 pixel-samples, a 4K frame's 480 samples per pixel)
+int grid_fine_resolution(const PtContext* ctx) {
+    const int coarse = grid_resolution(ctx);
+    if (ctx->grid_res_override > 0 || coarse < 2048 || ctx->num_triangles < kFineGridMinTriangles) return coarse;
+    return 4096;
 }
 
 PtStatus build_grid(PtContext* ctx) {
@@ -316,12 +341,18 @@ PtStatus build_grid(PtContext* ctx) {
     uint32_t total = 0, entries = 0;  // list words needed (cells with two or more triangles); all (cell, triangle) entries
     size_t cells = 0;
     // (a mesh that needed a coarser grid once keeps it until the next upload, so camera moves do not reallocate)
-    for (int res = (ctx->grid_res_reduced && g.res > 0) ? g.res : grid_resolution(ctx);; res /= 2, ctx->grid_res_reduced = true) {
+    const int preferred = ctx->grid_want_fine ? grid_fine_resolution(ctx) : grid_resolution(ctx);
+    for (int res = (ctx->grid_res_reduced && g.res > 0) ? g.res : preferred;; res /= 2, ctx->grid_res_reduced = true) {
         if (res < 32) return PT_OK;
         cells = (size_t)6 * res * res;
+        if (g.res != res && ctx->grid_spare.res == res) std::swap(g, ctx->grid_spare);  // the other resolution's arrays are at hand
         if (g.res != res) {
             PT_REQUIRE(!ctx->no_alloc, PT_ERR_STATE, "the direction grid must be rebuilt at %d cells per face edge (it has %d), which allocates: "
                        "render one frame of this view with pt_dispatch first", res, g.res);
+            // (coarse and fine of one mesh: the set not in use is kept instead of freed; a mesh whose lists forced a coarser
+            // grid than preferred has one resolution only)
+            if (g.res != 0 && ctx->grid_spare.res == 0 && !ctx->grid_res_reduced && grid_fine_resolution(ctx) != grid_resolution(ctx))
+                std::swap(g, ctx->grid_spare);
             free_grid(ctx);
             g.res = res;
             g.scan_tmp_bytes = pt_grid_scan_temp_bytes(cells);
@@ -379,6 +410,8 @@ PtStatus build_grid(PtContext* ctx) {
 void free_mesh(PtContext* ctx) {
     free_bvh(ctx);
     free_grid(ctx);
+    free_grid_arrays(ctx->grid_spare);
+    ctx->grid_want_fine = false;
     ctx->grid_wanted = false;
     ctx->grid_res_reduced = false;
     float** f[] = {&ctx->d_vertices, &ctx->d_tris, &ctx->d_vnormals, &ctx->d_gnormals, &ctx->d_cull, &ctx->d_tris_abs, &ctx->d_tris_live, &ctx->d_tris_grid};
@@ -422,6 +455,10 @@ PtStatus ensure_records(PtContext* ctx) {
     ctx->list_valid = false;  // new mesh or camera position: the tile costs will change
     ctx->costs_stale = true;
     ctx->dispatches_here = 0;
+    ctx->px_samples_here = 0.0;
+    // a new view starts with the grid that is quick to build -- unless the dispatch that brought the move is itself long enough
+    // to repay the fine one (pt_dispatch has looked: grid_fine_over_move)
+    ctx->grid_want_fine = ctx->grid_fine_over_move;
     return PT_OK;
 }
 
@@ -691,6 +728,7 @@ PtStatus pt_create(int32_t device, PtContext** out_ctx) {
     if (const char* g = getenv("PT_PRIMARY_CACHE")) ctx->primary_cache_enabled = g[0] != '0';
     if (const char* g = getenv("PT_GRID_OCC")) ctx->grid_occ_override = atoi(g) != 0;
     if (const char* g = getenv("PT_GRID_QUEUE")) ctx->grid_queue_override = atoi(g);
+    if (const char* g = getenv("PT_GRID_FINE_AFTER")) ctx->grid_fine_after = atof(g);
     if (const char* g = getenv("PT_FAIL_GRID_ALLOC")) ctx->fail_grid_alloc = atoi(g);
     if (const char* g = getenv("PT_GRID_RES")) ctx->grid_res_override = std::min(atoi(g), 8192);  // cell indices stay far below 2^32
     if (const char* l = getenv("PT_LANE_WALK")) ctx->lane_walk = l[0] == '0' ? 0 : (l[0] == '2' ? 2 : 1);
@@ -1270,10 +1308,26 @@ PtStatus pt_dispatch(PtContext* ctx, int32_t first_sample, int32_t num_samples, 
     // u_Samples is a float: beyond 2^24 consecutive indices stop being representable.
     PT_REQUIRE((int64_t)first_sample + (int64_t)(num_samples - 1) * stride <= (1 << 24), PT_ERR_INVALID_ARGUMENT,
                "sample index exceeds 2^24 (u_Samples is a float)");
+    // Large mesh, direction grid: once this camera position has gathered enough pixel-samples (this dispatch included) the grid
+    // is rebuilt at its fine resolution (grid_fine_resolution); both sets of arrays are kept, so only the first switch allocates.
+    const double my_px_samples = (double)ctx->win[2] * (double)ctx->win[3] / (double)(ctx->row_count > 1 ? ctx->row_count : 1) * (double)num_samples;
+    {
+        const bool moved = !ctx->records_valid || memcmp(ctx->uniforms.camera_position, ctx->records_ro, sizeof ctx->records_ro) != 0;
+        const bool eligible = ctx->grid_wanted && ctx->have_uniforms && ctx->shading_mode == PT_SHADE_REFERENCE &&
+                              grid_fine_resolution(ctx) != grid_resolution(ctx);
+        const bool enough = eligible && ctx->grid_fine_after >= 0.0 && (moved ? 0.0 : ctx->px_samples_here) + my_px_samples >= ctx->grid_fine_after;
+        if (moved) {
+            ctx->grid_fine_over_move = enough;   // (ensure_records resets the view's state and takes this over)
+        } else if (enough && !ctx->grid_want_fine) {
+            ctx->grid_want_fine = true;
+            ctx->grid_valid = false;             // rebuilt at the fine resolution by the update below
+        }
+    }
     {   // brings everything derived from mesh and camera up to date, which also tells whether the tile costs still apply
         PtKernelParams p;
         const Program* prog = nullptr;
         s = fill_params(ctx, &p, &prog);
+        ctx->grid_fine_over_move = false;
         if (s != PT_OK) return s;
     }
     if (ctx->timing) {
@@ -1303,6 +1357,7 @@ PtStatus pt_dispatch(PtContext* ctx, int32_t first_sample, int32_t num_samples, 
     }
     ctx->dispatches += 1;
     ctx->dispatches_here += 1;
+    ctx->px_samples_here += my_px_samples;
     return PT_OK;
 }
 

@@ -425,6 +425,65 @@ def test_block_bits_of_the_direction_grid_change_nothing(workload, size):
     assert rays["0"] == rays["1"] == rays[None]
 
 
+def test_fine_direction_grid_for_a_view_that_stays():
+    """A large mesh gets a finer direction grid (4096 cells per face edge instead of 2048) once a camera position has gathered
+    enough pixel-samples to repay its longer build; a camera move goes back to the coarse one, and both sets of arrays are kept.
+    With the threshold lowered (PT_GRID_FINE_AFTER) so that a small frame crosses it: the grid's entry count shows which one is
+    in use, the images and ray counts equal those of a context held to the coarse grid (PT_GRID_FINE_AFTER=-1) bit for bit at
+    every step, and the self-check finds the fine grid's answers equal to the loop over all triangles."""
+    import os
+    from pathtracer_amd import Tracer, capi, host_api
+    from pathtracer_amd.scenes import SceneData
+    scene = SceneData("instanced", 640, 360)
+    cam2 = host_api.camera(60.0, scene.width, scene.height, (150.0, -90.0, -1300.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0))
+
+    def run(fine_after):
+        old = os.environ.pop("PT_GRID_FINE_AFTER", None)
+        os.environ["PT_GRID_FINE_AFTER"] = fine_after
+        try:
+            t = Tracer(0)
+        finally:
+            os.environ.pop("PT_GRID_FINE_AFTER", None)
+            if old is not None:
+                os.environ["PT_GRID_FINE_AFTER"] = old
+        out = []
+        with t:
+            scene.upload(t)
+            t.target_create(scene.width, scene.height)
+            t.set_accel_mode(capi.ACCEL_GRID)
+
+            def step(first, n, verify=False):
+                t.dispatch(first, n, 1)
+                t.finish()
+                st = t.stats()
+                if verify:
+                    compared, bad_id, bad_t = t.verify_accel(1)
+                    assert compared >= scene.width * scene.height and (bad_id, bad_t) == (0, 0)
+                out.append((t.readback().copy(), st["rays"], st["grid_entries"]))
+
+            step(1, 4)                     # 0.9e6 pixel-samples: coarse
+            step(5, 4, verify=True)        # 1.8e6 with this dispatch: the fine grid is built for it
+            step(9, 4)                     # stays fine
+            t.set_uniforms(cam2, scene.num_triangles, 10)
+            t.target_clear()
+            step(1, 2, verify=True)        # new camera position: coarse again (arrays at hand)
+            step(3, 16)                    # long enough by itself: fine
+            t.set_uniforms(scene.camera, scene.num_triangles, 10)
+            t.target_clear()
+            step(1, 16, verify=True)       # a move brought by a dispatch that is long enough: fine at once
+        return out
+
+    switching, coarse = run("1.5e6"), run("-1")
+    for k, ((img, rays, _), (img0, rays0, _)) in enumerate(zip(switching, coarse)):
+        assert n_bit_mismatch(img, img0) == 0 and rays == rays0, f"step {k}"
+    e = [entries for _, _, entries in switching]
+    e0 = [entries for _, _, entries in coarse]
+    assert e0[0] == e0[1] == e0[2] and e0[3] == e0[4]       # the coarse grid of each camera position
+    assert e[0] == e0[0] and e[1] > e[0] and e[2] == e[1]   # coarse, then fine (more cells: more entries)
+    assert e[3] == e0[3] and e[4] > e[3]
+    assert e[5] == e[1]                                     # back at the first position, fine from the start
+
+
 @pytest.mark.parametrize("workload,size,spp", [("monkeyhead2", (480, 270), 6), ("suzanne", (640, 360), 5), ("instanced", (960, 540), 3),
                                                ("torus_distorted", (480, 270), 6)])
 def test_materials_mode_camera_rays_through_the_direction_grid(workload, size, spp):

@@ -4,7 +4,7 @@ out=gpurun_out/bench_workloads.jsonl
 : > $out
 timeout -k 10 200 python bench.py --lean --steps 10 --warmup 2 --workload monkeyhead2 >> $out
 timeout -k 10 200 python bench.py --lean --steps 10 --warmup 2 --workload suzanne >> $out
-timeout -k 10 200 python bench.py --lean --steps 10 --warmup 2 --workload instanced --spp 64 >> $out
+timeout -k 10 200 python bench.py --lean --steps 8 --warmup 3 --workload instanced --spp 256 >> $out
 timeout -k 10 200 python bench.py --lean --steps 10 --warmup 2 --workload world >> $out
 timeout -k 10 200 python bench.py --lean --steps 10 --warmup 2 --workload torus --spp 64 >> $out
 timeout -k 10 300 python bench.py --lean --steps 2 --warmup 1 --workload instanced --spp 4096 >> $out
