@@ -48,6 +48,11 @@ int RunRenderLoop(const RenderOptions& opt, Framebuffer& fb, RenderResult& resul
     } while (0)
 
     const int width = opt.width, height = opt.height;
+    // (Framebuffer keeps the reference's 16-bit width and height, Framebuffer.h:10-11)
+    if (width < 1 || height < 1 || width > 65535 || height > 65535) {
+        result.error = "image size " + std::to_string(width) + "x" + std::to_string(height) + " outside 1..65535 (Framebuffer holds 16-bit sizes)";
+        return 1;
+    }
     fb.create(width, height);
 
     // scene, as main() builds it (PathTracer.cpp:1160-1244)
