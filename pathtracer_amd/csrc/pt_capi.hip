@@ -214,6 +214,17 @@ namespace {
 
 constexpr size_t kCounterBytes = (size_t)PT_COUNTER_SLOTS * PT_COUNTER_STRIDE * sizeof(unsigned long long);
 constexpr int PT_MAX_SPLIT_FACTOR = 8;  // arrays of the scheduler are sized for this many split tiles per wave slot
+// Split factor of throughput-bound kernels (loop, direction grid, per-lane walk) on a view whose work is spread out: a tile is
+// split when its cost exceeds total / (factor x wave slots). Slightly below 1 (the kernels hold seven waves per SIMD where the
+// slots count eight, and the list starts the expensive tiles first, so a tile a little above a slot's share still ends
+// within the dispatch): on the 1080p Cornell box factor 1 split 686 tiles that sit right at the threshold and parked 170-230 MB of
+// samples per dispatch for nothing -- same time at 1, 0.85 and 0.7 on every workload (profiles/r02_split_factor_spread_ab.log),
+// no split tile and no parked sample at 0.85. PT_V_SPREAD_SPLIT sets it in experiment builds.
+#ifdef PT_V_SPREAD_SPLIT
+constexpr float kSpreadSplitFactor = PT_V_SPREAD_SPLIT;
+#else
+constexpr float kSpreadSplitFactor = 0.85f;
+#endif
 
 PtStatus bind(PtContext* ctx) {
     PT_REQUIRE(ctx != nullptr, PT_ERR_INVALID_ARGUMENT, "null context");
@@ -1182,7 +1193,7 @@ PtStatus dispatch_range(PtContext* ctx, int32_t first_sample, int32_t num_sample
             // at 4; 36 triangles through the hierarchy: 7.3 / 8.1; but 3,936 triangles at 1080p: 6.0 / 5.7, 968: 4.0 / 3.5, and
             // 6.1 / 3.9 at factor 16): factor 1, and 4 for a view found to be concentrated.
             const float base_factor = ctx->split_factor >= 0.f ? std::min(ctx->split_factor, (float)PT_MAX_SPLIT_FACTOR)
-                                                               : (p.bvh_nodes ? 4.0f : 1.0f);
+                                                               : (p.bvh_nodes ? 4.0f : kSpreadSplitFactor);
             const float eager_factor = p.bvh_nodes_abs ? 4.0f : (float)PT_MAX_SPLIT_FACTOR;
             const bool splitting = ctx->sched_mode == 2 && num_samples > 1;
             const int entry_bytes = is_materials(ctx->shading_mode) && prog->kind != PT_PROGRAM_WORLD ? 16 : 8;  // what a parked sample takes
@@ -1210,7 +1221,7 @@ PtStatus dispatch_range(PtContext* ctx, int32_t first_sample, int32_t num_sample
                     if (getenv("PT_DEBUG_SCHED"))
                         fprintf(stderr, "[pt sched] %d tiles, %d samples, costs from %lld samples, factor %g: %u items, %u split tiles\n", tiles,
                                 num_samples, (long long)ctx->cost_samples, (double)factor, c[0], c[1]);
-                    if (ctx->split_factor < 0.f && factor == 1.0f && c[1] >= (uint32_t)(ctx->wave_slots / 5)) {
+                    if (ctx->split_factor < 0.f && factor == kSpreadSplitFactor && c[1] >= (uint32_t)(ctx->wave_slots / 5)) {
                         factor = eager_factor;  // work concentrated in few tiles
                         ctx->concentrated = true;
                         continue;
@@ -1421,7 +1432,7 @@ PtStatus pt_dispatch_static(PtContext* ctx, int32_t first_sample, int32_t num_sa
         s = begin_pass(ctx, &p, &prog, first_sample + probe * stride, rest, stride);
         if (s != PT_OK) return s;
         const float factor = ctx->split_factor >= 0.f ? std::min(ctx->split_factor, (float)PT_MAX_SPLIT_FACTOR)
-                                                      : ((p.bvh_nodes || p.bvh_nodes_abs) ? 4.0f : 1.0f);
+                                                      : ((p.bvh_nodes || p.bvh_nodes_abs) ? 4.0f : kSpreadSplitFactor);
         size_t max_split = std::min<size_t>((size_t)(factor * (float)ctx->wave_slots), PT_STATIC_MAX_SPLIT);
         max_split = std::min(max_split, kStaticSampleBytes / slot_bytes);  // as many split tiles as the array can park
         if (p.grid_occ && ctx->grid_occ_override < 0)

@@ -24,6 +24,8 @@ VARIANTS = {
     "nounroll": ["-fno-unroll-loops"],
     "o2": ["-O2"],
     "countfull": ["-DPT_V_COUNT_FULL"],  # all-triangles loops: counts the tests past the wave-uniform back-face skip (tools/pmc_collect.py uses it)
+    "split07": ["-DPT_V_SPREAD_SPLIT=0.7f"],   # split factor of spread-out views 0.7 / 1 instead of 0.85
+    "split1": ["-DPT_V_SPREAD_SPLIT=1.0f"],
     "iters": ["-DPT_V_COUNT_ITERS"],   # direction grid: list-loop trips per wave in bvh_node_fetches, lanes with >1 test in bvh_triangle_fetches
 }
 
