@@ -75,12 +75,20 @@ FLOP = {
 GATHER_PEAK = (("l2", 4 << 20, 16800.0), ("infinity_cache", 256 << 20, 8600.0), ("hbm", 1 << 62, 8000.0))
 
 
+def code_only(text):
+    """C/C++ source without its comments and layout: string literals stay as they are, // and /* */ comments go, runs of white
+    space count as one blank."""
+    import re
+    text = re.sub(r'"(?:\\.|[^"\\\n])*"|//[^\n]*|/\*.*?\*/', lambda m: m.group(0) if m.group(0).startswith('"') else " ", text, flags=re.S)
+    return " ".join(text.split())
+
+
 def kernel_source_hash():
-    """Identifies the kernels a profile was taken from: sources + build flags."""
+    """Identifies the kernels a profile was taken from: the code of the sources (comments and layout left out) + build flags."""
     h = hashlib.sha256()
     for rel in ("pathtracer_amd/csrc/pt_kernels.hip", "pathtracer_amd/csrc/pt_internal.h", "pathtracer_amd/csrc/pt_grid.hip",
                 "pathtracer_amd/csrc/pt_bvh.hip", "pathtracer_amd/csrc/pt_capi.hip"):   # (the last: grid resolution, work list, launch sizes)
-        h.update(open(os.path.join(ROOT, rel), "rb").read())
+        h.update(code_only(open(os.path.join(ROOT, rel), "r", encoding="utf-8", errors="replace").read()).encode())
     from pathtracer_amd import build as ptbuild
     h.update(" ".join(ptbuild.DEVICE_FLAGS).encode())
     return h.hexdigest()[:16]

@@ -220,7 +220,7 @@ def rng_fixture(scene):
 
 
 def config4_cases():
-    """BASELINE configuration 4: catmark_torus_creases0.obj and the torus next to its deterministically distorted copy
+    """The benchmark's fourth configuration: catmark_torus_creases0.obj and the torus next to its deterministically distorted copy
     (pathtracer_amd/scenes.py builds it; the reference's data/distordedmesh/*.bin is loaded by nothing). Both fit the
     reference's own 1024-texel scene textures (64 / 128 triangles, 32 / 64 vertices), so the unmodified upload path serves.
     Geometric normals: the file has no vn."""

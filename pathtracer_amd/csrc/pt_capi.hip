@@ -218,7 +218,7 @@ constexpr int PT_MAX_SPLIT_FACTOR = 8;  // arrays of the scheduler are sized for
 // split when its cost exceeds total / (factor x wave slots). Slightly below 1 (the kernels hold seven waves per SIMD where the
 // slots count eight, and the list starts the expensive tiles first, so a tile a little above a slot's share still ends
 // within the dispatch): on the 1080p Cornell box factor 1 split 686 tiles that sit right at the threshold and parked 170-230 MB of
-// samples per dispatch for nothing -- same time at 1, 0.85 and 0.7 on every workload (profiles/r02_split_factor_spread_ab.log),
+// samples per dispatch for nothing -- same time at 1, 0.85 and 0.7 on every workload (tools/ab_bench.py, variants split1 and split07),
 // no split tile and no parked sample at 0.85. PT_V_SPREAD_SPLIT sets it in experiment builds.
 #ifdef PT_V_SPREAD_SPLIT
 constexpr float kSpreadSplitFactor = PT_V_SPREAD_SPLIT;

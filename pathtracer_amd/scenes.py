@@ -125,7 +125,7 @@ class SceneData:
         self.num_triangles = len(self.indices)
 
     def _init_torus_distorted(self, width, height):
-        """BASELINE configuration 4: catmark_torus_creases0.obj next to a distorted copy of itself, 3840x2160, the
+        """The benchmark's fourth configuration: catmark_torus_creases0.obj next to a distorted copy of itself, 3840x2160, the
         reference's camera and its z + 3 translation, geometric normals (the file has no vn)."""
         self.name, self.program = "torus_distorted", capi.PROGRAM_MESH
         self.width, self.height = width or 3840, height or 2160

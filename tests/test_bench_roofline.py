@@ -90,3 +90,15 @@ def test_tracked_counter_entries_belong_to_the_current_kernels_or_are_ignored(tm
     entry, note = bench.pmc_entry(key)
     assert entry is None and "stale" in note
     assert bench.pmc_entry("no|such|configuration")[0] is None
+
+
+def test_profile_key_ignores_comments_and_layout_but_not_code():
+    """The hash that ties a counter profile to the kernel sources looks at code only: a comment or a line break changes nothing,
+    a constant does; a comment marker inside a string literal is text."""
+    a = 'int f() { return 3; }  // three\nconst char* s = "a // b";\n'
+    b = '/* note */ int f()\n{\n    return 3;\n}\nconst char* s = "a // b";'
+    c = 'int f() { return 4; }\nconst char* s = "a // b";'
+    d = 'int f() { return 3; }\nconst char* s = "a";'
+    assert bench.code_only(a) == bench.code_only(b)
+    assert bench.code_only(a) != bench.code_only(c)
+    assert bench.code_only(a) != bench.code_only(d)

@@ -586,7 +586,7 @@ def test_self_check_of_every_structure(workload, size):
 
 
 def test_self_check_on_the_full_4k_million_triangle_frame():
-    """BASELINE configuration 5's frame: every camera ray of the 3840x2160 view of the 999,744-triangle scene and the first
+    """The frame of the benchmark's fifth configuration: every camera ray of the 3840x2160 view of the 999,744-triangle scene and the first
     generation of bounce rays, through the direction grid and through the LBVH, against the loop over all triangles."""
     from pathtracer_amd import Tracer
     from pathtracer_amd.scenes import SceneData

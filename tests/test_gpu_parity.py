@@ -833,7 +833,7 @@ CONFIG4 = ["torus_geo_128", "torus_distorted_geo_128", "torus_distorted_geo_256x
 @pytest.mark.parametrize("accel", [1, 2, 4])
 @pytest.mark.parametrize("name", CONFIG4)
 def test_config4_goldens_through_every_search_mode(tracer, name, accel):
-    """BASELINE configuration 4 (catmark torus + its distorted copy) against what the reference shader rendered on llvmpipe,
+    """The benchmark's fourth configuration (catmark torus + its distorted copy) against what the reference shader rendered on llvmpipe,
     through the all-triangles loop, the LBVH and the direction grid: ids, distances and radiance bit for bit, the latter from one
     multi-sample dispatch per checkpoint."""
     fx = load_case(name)

@@ -176,7 +176,7 @@ def test_shader_stage_selection(tmp_path):
 
 
 def test_config4_scene_is_the_one_the_goldens_were_rendered_from():
-    """The torus + distorted-copy workload (BASELINE configuration 4) is built from a fixed integer LCG, so it is the same on
+    """The torus + distorted-copy workload (the benchmark's fourth configuration) is built from a fixed integer LCG, so it is the same on
     every machine: its arrays equal those stored with the llvmpipe goldens."""
     import numpy as np
     from helpers import load_case
