@@ -124,7 +124,7 @@ struct PtContext {
                                 // kept so that going back and forth between the two allocates nothing
     bool grid_want_fine = false;   // this camera position has gathered enough samples for the fine grid to pay (pt_dispatch decides)
     bool grid_fine_over_move = false;  // set by pt_dispatch around its own update of the records (see ensure_records)
-    double grid_fine_after = 4.0e9;    // pixel-samples at one camera position from which the fine grid is used (PT_GRID_FINE_AFTER=x
+    double grid_fine_after = 2.0e9;    // pixel-samples at one camera position from which the fine grid is used (PT_GRID_FINE_AFTER=x
                                        // sets it, for tests and measurements; negative: never)
     double px_samples_here = 0.0;  // pixel-samples dispatched since the mesh or the camera position last changed
     bool grid_wanted = false;   // pt_build_accel was called for this mesh
@@ -329,10 +329,10 @@ int grid_resolution(const PtContext* ctx) {
 
 // Resolution for a view that stays: a finer grid keeps paying on a large mesh (1M triangles at 4K, ms per 64-spp dispatch at
 // 2048 / 3072 / 4096 / 8192: 1.61 / 1.36 / 1.28 / 1.19), but its build grows with the cell count (first frame after a camera
-// move: 1.24 / 2.03 / 3.19 ms at 2048 / 3072 / 4096), and on meshes of 100-500 thousand triangles the gain per sample is a
+// move: 0.97 / 1.44 / 2.10 ms at 2048 / 3072 / 4096), and on meshes of 100-500 thousand triangles the gain per sample is a
 // quarter of that. So 4096 serves large meshes only, and only once a camera position has gathered the pixel-samples that repay
 // the longer build (pt_dispatch decides, PtContext::grid_fine_after); a camera that keeps moving stays with 2048.
-constexpr int32_t kFineGridMinTriangles = 750000;   // (PtContext::grid_fine_after: 4e9 pixel-samples, a 4K frame's 480 samples per pixel)
+constexpr int32_t kFineGridMinTriangles = 750000;   // (PtContext::grid_fine_after: 2e9 pixel-samples, a 4K frame's 240 samples per pixel)
 int grid_fine_resolution(const PtContext* ctx) {
     const int coarse = grid_resolution(ctx);
     if (ctx->grid_res_override > 0 || coarse < 2048 || ctx->num_triangles < kFineGridMinTriangles) return coarse;
