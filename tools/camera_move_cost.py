@@ -14,13 +14,15 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="instanced")
+    ap.add_argument("--variant", default=None, help="an experimental library built by tools/ab_bench.py --build")
+    ap.add_argument("--shading", default="reference", choices=["reference", "materials"])
     args = ap.parse_args()
     import numpy as np
     from pathtracer_amd import Tracer
     from pathtracer_amd.scenes import SceneData
     scene = SceneData(args.workload)
-    t = Tracer(0)
-    scene.upload(t)
+    t = Tracer(0, os.path.join(ROOT, "pathtracer_amd", "lib", f"libpt_hip__{args.variant}.so")) if args.variant else Tracer(0)
+    scene.upload(t, shading=args.shading)
     t.target_create(scene.width, scene.height)
 
     def frame():
@@ -38,7 +40,7 @@ def main():
         cam[3:6] += np.float32(0.01 * (k + 1))      # lower-left corner moves with it
         t.set_uniforms(cam, scene.num_triangles, 10)
         moved.append(frame())
-    print(json.dumps({"workload": args.workload, "triangles": scene.num_triangles, "plain_frame_ms": round(plain, 3),
+    print(json.dumps({"workload": args.workload, "shading": args.shading, "library": args.variant or "current", "triangles": scene.num_triangles, "plain_frame_ms": round(plain, 3),
                       "frame_after_camera_move_ms": [round(m, 3) for m in moved], "grid_entries": t.stats()["grid_entries"]}))
     t.close()
 
