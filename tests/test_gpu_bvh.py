@@ -527,6 +527,9 @@ def test_materials_mode_camera_rays_through_the_direction_grid(workload, size, s
         t.finish()
         out["moved"] = t.readback().copy()
         out["grid_entries"] = t.stats()["grid_entries"]
+        # (without the grid this is the loop over the compacted records, which no materials dispatch has brought up to date
+        # for the new position: the call has to do that itself)
+        out["ids_moved"], out["t_moved"] = t.readback_primary()
         return out
 
     results = {}
@@ -549,6 +552,8 @@ def test_materials_mode_camera_rays_through_the_direction_grid(workload, size, s
         assert n_bit_mismatch(g["moved"], o["moved"]) == 0 and n_bit_mismatch(g["moved"], g["full"]) > 0
         assert g["rays"] == o["rays"]
         assert np.array_equal(g["ids"], o["ids"]) and np.array_equal(g["t"].view(np.uint32), o["t"].view(np.uint32))
+        assert np.array_equal(g["ids_moved"], o["ids_moved"]) and np.array_equal(g["t_moved"].view(np.uint32), o["t_moved"].view(np.uint32))
+    assert not np.array_equal(g["ids_moved"], g["ids"])
     assert g["rays"] > W * H * (spp + 3)
     assert g["grid_entries"] > 0 and results["walk"]["grid_entries"] == 0 and results["auto_walk"]["grid_entries"] == 0
 
