@@ -16,10 +16,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cameras", type=int, default=40)
     ap.add_argument("--spp", type=int, default=6)
+    ap.add_argument("--seed", type=int, default=2024)
     args = ap.parse_args()
     from pathtracer_amd import Tracer, capi, host_api
     from pathtracer_amd.scenes import SceneData
-    rng = np.random.default_rng(2024)
+    rng = np.random.default_rng(args.seed)
     total_bad, total_rays = 0, 0
     for workload, W, H, modes in (("cornell", 320, 240, (capi.ACCEL_BRUTE, capi.ACCEL_BVH)), ("monkeyhead2", 320, 240, (capi.ACCEL_BRUTE, capi.ACCEL_BVH)),
                                   ("suzanne", 320, 240, (capi.ACCEL_BVH,)), ("instanced", 640, 360, (capi.ACCEL_BVH,))):
