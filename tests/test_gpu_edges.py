@@ -380,3 +380,32 @@ def test_tile_costs_are_fresh_after_a_move_and_short_dispatches(tracer, capfd):
     ref, _ = po.render(scene, u2, 1, 67, threads=8)
     assert n_bit_mismatch(tracer.readback(), ref) == 0
     tracer.program_destroy(prog)
+
+
+@pytest.mark.parametrize("workload,size,spp", [("cornell", (7680, 4320), 2), ("cornell", (65535, 5), 3), ("monkeyhead2", (3, 30000), 3)])
+def test_targets_far_beyond_the_benchmark_sizes(workload, size, spp):
+    """A frame four times the largest benchmark frame (518,400 tiles) and the two thinnest targets a 16-bit image size allows
+    (aspect ratios of 13,107 and 1/10,000: nearly every tile is cut by the image's edge), each whole frame against the oracle:
+    camera-ray ids and distances, radiance and ray count, bit for bit."""
+    from pathtracer_amd import Tracer
+    from pathtracer_amd.scenes import SceneData
+    scene = SceneData(workload, *size)
+    W, H = scene.width, scene.height
+    assert (W, H) == size
+    with Tracer(0) as t:
+        scene.upload(t)
+        t.target_create(W, H)
+        ids, ts = t.readback_primary()
+        t.dispatch(1, spp, 1)
+        t.finish()
+        img = t.readback()
+        rays = t.stats()["rays"]
+    sc = po.Scene(scene.vertices, scene.indices, scene.spheres, scene.materials)
+    u = po.uniforms(scene.camera, W, H, scene.num_triangles, 10, po.VARIANT_MESH, scene.normal_mode)
+    oids, ots, _ = po.primary(sc, u, threads=16)
+    assert np.array_equal(ids, oids) and n_bit_mismatch(ts, ots) == 0
+    assert (oids >= 0).any()
+    del oids, ots
+    ref, orays = po.render(sc, u, 1, spp, threads=16)
+    assert n_bit_mismatch(img, ref) == 0
+    assert rays == orays > W * H * spp
