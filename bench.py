@@ -15,8 +15,8 @@ merged by one RCCL all-reduce per step inside the timed region, beside the rende
 the ranks share the rows of ONE frame in interleaved blocks (strong scaling, bit-identical to one GPU), merged by an
 all-gather of the owned rows, also beside the next step.
 
-Prints one JSON line on rank 0: whole-job Mrays/s (ray = one closest-hit query = one bounce-loop iteration, the
-reference's definition), the roofline of the render kernel from the work it executed, and a CPU baseline from the oracle.
+Prints one JSON line on rank 0: whole-job Mrays/s (ray = one closest-hit query actually evaluated; the count by the
+reference's definition, one per bounce-loop iteration with reused camera-ray answers included, is reported beside it), the roofline of the render kernel from the work it executed, and a CPU baseline from the oracle.
 """
 import argparse
 import hashlib
@@ -402,7 +402,7 @@ def side_run(local_rank, workload, shading, spp, steps, width=None, height=None)
     pmc, note = pmc_entry(key)
     n = max(1, st["dispatches"])
     return {"workload": f"{sc.name} {sc.width}x{sc.height}, {sc.num_triangles} triangles, {spp} spp per dispatch, shading {shading} (mean of {steps} dispatches)",
-            "Mrays_per_s": st["rays"] / n / ms * 1e-3, "evaluated_Mrays_per_s": st["rays_traced"] / n / ms * 1e-3,
+            "Mrays_per_s": st["rays_traced"] / n / ms * 1e-3, "reference_definition_Mrays_per_s": st["rays"] / n / ms * 1e-3,
             "kernel_ms": ms, "rays_per_sample": st["rays"] / max(1, st["samples"]),
             "roofline": roofline(st, ms, sc, shading, pmc, note)}
 
@@ -564,7 +564,7 @@ def main():
                "loop": "the shader's loop over all triangles", "loop_from": "the shader's loop over all triangles", "spheres": "the reference's 10 spheres (IntersectWorld)"}[which_kernel(st, scene.program, args.shading)[1]]
         out = {
             "metric": "Mrays/s (whole node) at 1080p Cornell box + 1M-tri scene, 1/2/4/8 MI355X",
-            "value": rays / elapsed * 1e-6,
+            "value": traced / elapsed * 1e-6,
             "unit": "Mrays/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -584,17 +584,18 @@ def main():
                                                                            (", overlapped with the next step's rendering" if overlap else "")
                                                                            if tile_split else f"sample split over {world} GPUs + RCCL all-reduce of the sums" +
                                                                            (", overlapped with the next step's rendering" if merger is not None else ""))},
-            "value_evaluated": traced / elapsed * 1e-6,
+            "value_reference_definition": rays / elapsed * 1e-6,
             "host_issue_ms_per_step": {"median": float(np.median(issue_ms)), "max": float(np.max(issue_ms)),
                                        "note": "time this rank's host spent inside each step's calls (dispatch and merge submission). With the "
                                                "library's timing switched on, as here, a dispatch first collects the previous dispatch's events, so "
                                                "the host runs one step ahead of the device and the median is the device's step time; what matters is "
                                                "how far the maximum lies above it (a dispatch that rebuilds its work list also waits for two counters)"},
-            "rays_definition": "value: closest-hit queries as the reference counts them, one per bounce-loop iteration of every sample "
-                               "(PathTracer.cpp:947). The shader has no pixel jitter, so the first query of every sample of a pixel "
-                               "is the same; it is evaluated once per dispatch and pixel and reused (bit-identical image). "
-                               "value_evaluated counts only the queries actually evaluated (the figure to compare across tracers); "
-                               "'no_primary_reuse' is the same step with every query evaluated.",
+            "rays_definition": "value: closest-hit queries actually EVALUATED per second (a ray is counted where it is traced, as the "
+                               "reference's CPU tracer does at PathTracer.cpp:947). The shader has no pixel jitter, so the first query "
+                               "of every sample of a pixel is the same; it is evaluated once per dispatch and pixel and reused "
+                               "(bit-identical image) and counts once. value_reference_definition counts one query per bounce-loop "
+                               "iteration of every sample, reused ones included (what the reference's own loop would have traced for "
+                               "this image); 'no_primary_reuse' is the same step with every query evaluated.",
             "primary_reuse": True,
             "no_primary_reuse": None if plain is None else
                                 {"value": plain["rays"] / 3 / plain_elapsed * 1e-6 * world, "unit": "Mrays/s", "ms_per_step": plain_elapsed * 1e3,

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 5
+#define PT_ABI_VERSION 6
 
 typedef enum PtStatus {
     PT_OK = 0,
@@ -141,6 +141,9 @@ typedef struct PtStats {
     float last_dispatch_ms;    /* device time of the most recent pt_dispatch (scheduler, render and fold kernels);
                                   0 unless timing is enabled */
     double total_dispatch_ms;  /* sum over dispatches since the last reset; 0 unless timing is enabled */
+    uint32_t bvh_sweeps;       /* bottom-up sweeps the last pt_build_accel ran to box its hierarchy, a multiple of 8: an upper bound
+                                  of the hierarchy's height (0 = no hierarchy) */
+    uint32_t reserved;
 } PtStats;
 
 typedef struct PtContext PtContext; /* opaque */
@@ -236,7 +239,9 @@ PtStatus pt_set_window(PtContext* ctx, int32_t x0, int32_t y0, int32_t w, int32_
 PtStatus pt_set_row_interleave(PtContext* ctx, int32_t block_rows, int32_t index, int32_t count);
 PtStatus pt_set_accum_mode(PtContext* ctx, PtAccumMode mode);
 /* PT_PROGRAM_CPU_TRACER only: seed of its random number generator (default 1) and the camera ray's maxt, far - near of
- * Camera::initialize (PathTracer.cpp:709-716, 745; default 100 - 0.1 as at :1161). Replaces srand() (PathTracer.cpp:1216). */
+ * Camera::initialize (PathTracer.cpp:709-716, 745; default 100 - 0.1 as at :1161). Stands where the reference seeds the stream
+ * its render loop draws from, srand(2 ^ 24 - 1) at PathTracer.cpp:1297 (an XOR: srand(21)); the value has no correspondence to
+ * the reference's, because the generator here is counter-based and not libc's. */
 PtStatus pt_set_cpu_tracer(PtContext* ctx, uint32_t seed, float ray_max_t);
 
 /* ---- per-frame: replaces PathTracer.cpp:1370-1403 ------------------------------------------------------ */
@@ -268,7 +273,11 @@ PtStatus pt_dispatch(PtContext* ctx, int32_t first_sample, int32_t num_samples, 
  * must exist already: target, scene, and -- for the direction grid -- arrays large enough for the current camera position
  * (one pt_dispatch of the view makes them; otherwise PT_ERR_STATE and nothing is rendered). It keeps no tile costs between
  * calls: a range of 32 samples or more is two launches (8 samples, then the rest scheduled by their costs), shorter ones one.
- * All contexts on a GPU share that GPU's array: calls that overlap on one GPU (two streams, two threads) race. */
+ * An error found after the first launch of a long range (a HIP failure) leaves the first 8 samples of the range folded into the
+ * image; PtStats::dispatches counts only calls that succeeded.
+ * All contexts on a GPU share that GPU's array. A call made while ANOTHER context's pt_dispatch_static is still running on the
+ * same GPU returns PT_ERR_STATE and renders nothing (wait for that context with pt_finish first); calls of one context follow
+ * each other on its stream. */
 PtStatus pt_dispatch_static(PtContext* ctx, int32_t first_sample, int32_t num_samples, int32_t stride);
 /* Replaces glFinish (PathTracer.cpp:1403): waits for the stream and reports any kernel fault. */
 PtStatus pt_finish(PtContext* ctx);
@@ -277,6 +286,13 @@ PtStatus pt_finish(PtContext* ctx);
 
 /* Copies the current image (the one the last pass wrote) to host: width*height*4 floats, row 0 = bottom. */
 PtStatus pt_readback_rgba32f(PtContext* ctx, float* dst);
+/* The reverse of pt_readback_rgba32f: `src` (width*height*4 floats, row 0 = bottom) becomes the current image, the one the next
+ * pass reads as its previous result. The reference cannot do this (its accumulation textures, PathTracer.cpp:1136-1152, are only
+ * ever rendered into), but those textures and the frame counter `samples` (PathTracer.cpp:1300,1305) are all the state its
+ * progressive render has: a host that saved an image after n passes continues it, in this or another context, by uploading it
+ * and dispatching with first_sample = n + 1 -- the result equals an uninterrupted run bit for bit. Synchronous like the scene
+ * uploads. */
+PtStatus pt_upload_rgba32f(PtContext* ctx, const float* src);
 /* Replaces the present quad (PathTracer.cpp:1473-1491 with data/shaders/copy.fs:12-20): display colour
  * pow(rgb, 0.454545) of the current image, converted to 8 bits per channel as an RGBA8 render target does, copied to
  * host as width*height RGBA bytes, row 0 = bottom. The reference draws this into its window; a host shows or saves it. */

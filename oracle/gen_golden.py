@@ -284,6 +284,31 @@ def monkey_materials_case():
     return ("monkey_materials_128", scene, cam, 128, 128, po.VARIANT_MESH, po.NORMALS_VERTEX, [1, 2, 16], None)
 
 
+MONKEY_TABLE = np.array([[0.5, 0.5, 0.5, 0.0], [0.85, 0.3, 0.2, 0.0], [0.25, 0.7, 0.35, 0.0], [1.0, 0.9, 0.7, 3.0]], np.float32)
+
+
+def config3_materials_cases():
+    """The benchmark's third configuration in the diffuse/emissive mode: monkeyhead2.obj and suzanne.obj at 1920x1080 (64x64 crops
+    on their silhouettes) and suzanne as a whole small frame. Neither file brings materials (monkeyhead2.mtl is empty, suzanne's
+    monkey.mtl is not in the reference), so the MTL rule gives every triangle the grey row; as in monkey_materials_128 three more
+    rows (two albedos and an emitter) are dealt to the triangles by index so that every branch of the mode runs. suzanne.obj has
+    more normals than positions (the reference's pairing of the two does not apply): geometric normals."""
+    sph, _ = po.reference_spheres_and_materials()
+    ref_cam = lambda W, H: po.camera(60.0, W, H, (0, 0, 0), (0, 0, 1), (0, 1, 0))
+    out = []
+    for obj, nm in (("monkeyhead2", po.NORMALS_VERTEX), ("suzanne", po.NORMALS_GEOMETRIC)):
+        d, _ = run_obj_dump(obj)
+        v, i = po.mesh_from_obj_arrays(d["v"], d["idx_v"], d["vn"] if nm == po.NORMALS_VERTEX else None)
+        t = np.arange(len(i))
+        scene = po.Scene(v, i, sph, MONKEY_TABLE, np.where(t % 11 == 5, 3, t % 3).astype(np.int32))
+        short = "monkey" if obj == "monkeyhead2" else obj
+        out.append((f"{short}_materials_1080p_crop", scene, ref_cam(1920, 1080), 1920, 1080, po.VARIANT_MESH, nm, [1, 4],
+                    (1130, 700, 64, 64) if obj == "monkeyhead2" else (1270, 540, 64, 64)))
+        if obj == "suzanne":
+            out.append(("suzanne_materials_96", scene, ref_cam(96, 96), 96, 96, po.VARIANT_MESH, nm, [1, 2], None))
+    return out
+
+
 def case_shading(name):
     return 2 if "materials_unit" in name else (1 if "materials" in name else 0)
 
@@ -292,7 +317,7 @@ def only(names):
     """Generates the named cases and leaves every other fixture as it is (python3 oracle/gen_golden.py --only a,b)."""
     path = f"{GOLD}/generation_report.json"
     report = json.load(open(path)) if os.path.exists(path) else []
-    for (name, sc, cam, W, H, variant, nm, spp, crop) in config4_cases() + [tiny_materials_case(), unit_materials_case(), monkey_materials_case()]:
+    for (name, sc, cam, W, H, variant, nm, spp, crop) in config4_cases() + [tiny_materials_case(), unit_materials_case(), monkey_materials_case()] + config3_materials_cases():
         if name not in names:
             continue
         fx, rep = render_case(name, sc, cam, W, H, variant, nm, spp, crop, shading_mode=case_shading(name))
@@ -370,7 +395,7 @@ def main():
         np.savez_compressed(f"{GOLD}/case_{name}.npz", **fx)
         report.append(rep)
 
-    for (name, sc, cam, W, H, variant, nm, spp, crop) in config4_cases() + [tiny_materials_case(), unit_materials_case(), monkey_materials_case()]:
+    for (name, sc, cam, W, H, variant, nm, spp, crop) in config4_cases() + [tiny_materials_case(), unit_materials_case(), monkey_materials_case()] + config3_materials_cases():
         fx, rep = render_case(name, sc, cam, W, H, variant, nm, spp, crop, shading_mode=case_shading(name))
         np.savez_compressed(f"{GOLD}/case_{name}.npz", **fx)
         report.append(rep)

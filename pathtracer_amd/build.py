@@ -19,7 +19,8 @@ CSRC = os.path.join(HERE, "csrc")
 HOST = os.path.join(HERE, "host")
 LIB = os.path.join(HERE, "lib")
 
-HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+HIPCC = os.environ.get("HIPCC", os.path.join(ROCM, "bin", "hipcc"))
 DEVICE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
                 "-fgpu-flush-denormals-to-zero", "-fno-fast-math", "-fno-slp-vectorize", "-fvisibility=hidden", "-Wall", "-Wextra",
                 "-Wno-unused-parameter"]
@@ -70,8 +71,11 @@ def build_host(force=False):
         return None
     if not force and not _newer(out, srcs + hdrs + [os.path.join(ROOT, "include", "pt_hip.h"), __file__]):
         return out
-    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall", "-Wextra",
-           f"-I{os.path.join(ROOT, 'include')}", "-o", out] + srcs + [f"-L{LIB}", "-lpt_hip", "-Wl,-rpath,$ORIGIN"]
+    # (MultiGpu.cpp calls the HIP runtime for streams, events and copies and takes RCCL's types from its header; librccl itself is
+    # opened at run time)
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall", "-Wextra", "-pthread", "-D__HIP_PLATFORM_AMD__",
+           f"-I{os.path.join(ROOT, 'include')}", f"-I{ROCM}/include", "-o", out] + srcs + \
+          [f"-L{LIB}", "-lpt_hip", f"-L{ROCM}/lib", "-lamdhip64", "-ldl", "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{ROCM}/lib"]
     _run(cmd)
     return out
 

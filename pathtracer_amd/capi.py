@@ -32,7 +32,7 @@ class PtStats(C.Structure):
                 ("bvh_triangle_fetches", C.c_uint64), ("grid_triangle_tests", C.c_uint64), ("grid_entries", C.c_uint64),
                 ("shaded_hits", C.c_uint64), ("loop_triangle_visits", C.c_uint64), ("loop_full_tests", C.c_uint64), ("lane_walk_records", C.c_uint64),
                 ("dispatches", C.c_uint32),
-                ("last_dispatch_ms", C.c_float), ("total_dispatch_ms", C.c_double)]
+                ("last_dispatch_ms", C.c_float), ("total_dispatch_ms", C.c_double), ("bvh_sweeps", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class PtError(RuntimeError):
@@ -74,6 +74,7 @@ SIGNATURES = {
     "pt_dispatch_static": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "pt_finish": (C.c_int, [C.c_void_p]),
     "pt_readback_rgba32f": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pt_upload_rgba32f": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pt_present_rgba8": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pt_current_image": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "pt_readback_primary": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -244,6 +245,13 @@ class Tracer:
         check(self._lib.pt_readback_rgba32f(self._ctx, out.ctypes.data), self._lib)
         return out
 
+    def upload_image(self, rgba):
+        """Makes `rgba` ([height, width, 4] float32) the current image: the state a saved progressive render continues from."""
+        a = np.ascontiguousarray(rgba, np.float32)
+        if a.shape != (self.height, self.width, 4):
+            raise ValueError(f"image of shape {a.shape} for a {self.width}x{self.height} target")
+        check(self._lib.pt_upload_rgba32f(self._ctx, a.ctypes.data), self._lib)
+
     def present(self):
         out = np.empty((self.height, self.width, 4), np.uint8)
         check(self._lib.pt_present_rgba8(self._ctx, out.ctypes.data), self._lib)
@@ -269,7 +277,7 @@ class Tracer:
         return {"rays": s.rays, "rays_traced": s.rays_traced, "samples": s.samples, "lane_slots": s.lane_slots, "bvh_node_fetches": s.bvh_node_fetches,
                 "bvh_triangle_fetches": s.bvh_triangle_fetches, "grid_triangle_tests": s.grid_triangle_tests,
                 "grid_entries": s.grid_entries, "shaded_hits": s.shaded_hits, "loop_triangle_visits": s.loop_triangle_visits,
-                "loop_full_tests": s.loop_full_tests, "lane_walk_records": s.lane_walk_records, "dispatches": s.dispatches,
+                "loop_full_tests": s.loop_full_tests, "lane_walk_records": s.lane_walk_records, "dispatches": s.dispatches, "bvh_sweeps": s.bvh_sweeps,
                 "last_dispatch_ms": s.last_dispatch_ms, "total_dispatch_ms": s.total_dispatch_ms}
 
     def reset_stats(self):

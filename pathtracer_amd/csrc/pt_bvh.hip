@@ -350,13 +350,26 @@ struct HostBox {
 
 struct SahBuilder {
     static constexpr int kBins = 16;
+    // ranges deeper than this are halved instead of split by cost, so the tree's height stays below kMaxCostDepth + log2(n) + 1:
+    // the walks keep their stacks in fixed arrays (PT_BVH_STACK entries per wave), and a mesh whose centroids cluster
+    // geometrically (or whose boxes have no area, so that every plane costs the same) would otherwise give one level per triangle
+    static constexpr int kMaxCostDepth = 40;
     const float* tri_box;   // n x 6
+
+    // bin of a centroid coordinate: clamped while still a float, so a NaN or a coordinate far outside the sampled bounds lands in
+    // bin 0 or the last bin on every compiler (the conversion of an out-of-range float to int is undefined); the binning pass and
+    // the partition must agree, so both use this
+    static int bin_of(float c, float lo, float scale) {
+        const float f = (c - lo) * scale;
+        if (!(f > 0.f)) return 0;
+        return f >= (float)kBins ? kBins - 1 : (int)f;
+    }
     uint32_t* order;
     int* child;
     int* range;
 
     // where the range [first, last] is cut: the first position of its right part
-    int split(int first, int last) const {
+    int split(int first, int last, int depth) const {
         const int count = last - first + 1;
         // a large range picks its plane from every stride-th triangle (16,384 or more of them); all of them are then partitioned
         const int stride = count >= (1 << 17) ? count >> 14 : 1;
@@ -371,7 +384,7 @@ struct SahBuilder {
         }
         int best_axis = -1, best_bin = 0;
         float best_cost = 3.0e38f, scale[3];
-        if (count > 2) {
+        if (count > 2 && depth < kMaxCostDepth) {
             HostBox bins[3][kBins];
             int counts[3][kBins];
             for (int k = 0; k < 3; ++k) {
@@ -383,7 +396,7 @@ struct SahBuilder {
                 const float* b = tri_box + 6 * (size_t)order[p];
                 for (int k = 0; k < 3; ++k) {
                     const float c = 0.5f * b[k] + 0.5f * b[3 + k];
-                    const int j = std::min(kBins - 1, std::max(0, (int)((c - clo[k]) * scale[k])));
+                    const int j = bin_of(c, clo[k], scale[k]);
                     bins[k][j].add(b);
                     ++counts[k][j];
                 }
@@ -413,7 +426,7 @@ struct SahBuilder {
             uint32_t* mid = std::partition(order + first, order + last + 1, [&](uint32_t id) {
                 const float* b = tri_box + 6 * (size_t)id;
                 const float c = 0.5f * b[k] + 0.5f * b[3 + k];
-                return std::min(kBins - 1, std::max(0, (int)((c - clo[k]) * scale[k]))) <= best_bin;
+                return bin_of(c, clo[k], scale[k]) <= best_bin;
             });
             const int at = (int)(mid - order);
             if (at > first && at <= last) return at;
@@ -440,26 +453,26 @@ struct SahBuilder {
     }
 
     // the subtree over [first, last] (two triangles or more), its root at index `node`
-    void build(int node, int first, int last, std::vector<std::array<int, 3>>* defer, int defer_below) {
-        struct Item { int node, first, last; };
+    void build(int node, int first, int last, int depth0, std::vector<std::array<int, 4>>* defer, int defer_below) {
+        struct Item { int node, first, last, depth; };
         std::vector<Item> stack;
-        stack.push_back({node, first, last});
+        stack.push_back({node, first, last, depth0});
         while (!stack.empty()) {
             const Item it = stack.back();
             stack.pop_back();
             if (defer && it.last - it.first + 1 <= defer_below) {   // left to a worker thread
-                defer->push_back({it.node, it.first, it.last});
+                defer->push_back({it.node, it.first, it.last, it.depth});
                 continue;
             }
-            const int at = split(it.first, it.last);
+            const int at = split(it.first, it.last, it.depth);
             const int left_count = at - it.first, right_count = it.last - at + 1;
             range[2 * it.node] = it.first;
             range[2 * it.node + 1] = it.last;
             const int left_node = it.node + 1, right_node = it.node + left_count;   // (a subtree over c triangles has c - 1 nodes)
             child[2 * it.node] = left_count == 1 ? ~it.first : left_node;
             child[2 * it.node + 1] = right_count == 1 ? ~at : right_node;
-            if (left_count > 1) stack.push_back({left_node, it.first, at - 1});
-            if (right_count > 1) stack.push_back({right_node, at, it.last});
+            if (left_count > 1) stack.push_back({left_node, it.first, at - 1, it.depth + 1});
+            if (right_count > 1) stack.push_back({right_node, at, it.last, it.depth + 1});
         }
     }
 };
@@ -473,7 +486,8 @@ hipError_t finish_topology(const PtBvhBuild& b, hipStream_t stream, int32_t* out
     int remaining = n - 1;
     e = hipMemcpyAsync(b.remaining, &remaining, sizeof(int), hipMemcpyHostToDevice, stream);
     if (e != hipSuccess) return e;
-    // The tree height is at most 63 + 32 levels (63-bit codes, then 32-bit positions); sweeps run in groups of 8 between checks.
+    // One sweep per level of the tree. The Morton builder's trees have at most 63 + 32 levels (63-bit codes, then 32-bit
+    // positions), the host builder's at most SahBuilder::kMaxCostDepth + log2(n) + 1; sweeps run in groups of 8 between checks.
     int pass = 1;
     while (remaining > 0) {
         if (pass > 4096) return hipErrorUnknown;  // cannot happen for a well-formed hierarchy; never spin forever
@@ -554,14 +568,14 @@ hipError_t pt_bvh_build_topology_sah(const PtBvhBuild& b, hipStream_t stream, in
     // The top of the tree on this thread, down to subtrees of at most n / 64 triangles; then the subtrees, which work on disjoint
     // parts of every array (a subtree's node indices follow from its position, so the result does not depend on which thread
     // built what).
-    std::vector<std::array<int, 3>> parts;   // node, first, last
+    std::vector<std::array<int, 4>> parts;   // node, first, last, depth
     try {
-        sb.build(0, 0, n - 1, threads > 1 && n >= 4096 ? &parts : nullptr, std::max(2, n / 64));
+        sb.build(0, 0, n - 1, 0, threads > 1 && n >= 4096 ? &parts : nullptr, std::max(2, n / 64));
     } catch (const std::exception&) {
         return hipErrorOutOfMemory;
     }
     ms_top = ms_since(t_start);
-    if (!parallel_for(parts.size(), [&](size_t k) { sb.build(parts[k][0], parts[k][1], parts[k][2], nullptr, 0); })) return hipErrorOutOfMemory;
+    if (!parallel_for(parts.size(), [&](size_t k) { sb.build(parts[k][0], parts[k][1], parts[k][2], parts[k][3], nullptr, 0); })) return hipErrorOutOfMemory;
     ms_subtrees = ms_since(t_start) - ms_top;
     const auto t_wide = now();
     // Wide nodes: a node's two children, then the child with the largest box replaced by its own two children until there are

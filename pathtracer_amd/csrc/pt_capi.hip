@@ -38,6 +38,14 @@ constexpr size_t kStaticSampleBytes = PT_STATIC_SCRATCH_BYTES - kStaticSamplesOf
 constexpr int kMaxDevices = 64;
 void* g_scratch_ptr[kMaxDevices] = {};  // device address of `scratch` on each GPU (each holds its own copy)
 std::mutex g_scratch_mutex;
+// Who used a GPU's scratch array last: the context and the event it recorded behind its launches. Another context's
+// pt_dispatch_static on the same GPU is refused while that event has not completed (the array is shared, see pt_hip.h).
+struct ScratchUse {
+    PtContext* owner = nullptr;
+    hipEvent_t done = nullptr;
+    bool issuing = false;   // the owner is inside pt_dispatch_static right now (its event is not recorded yet)
+};
+ScratchUse g_scratch_use[kMaxDevices];
 
 // the modes in which Shade() keeps the fetched material and moves the ray origin
 inline bool is_materials(PtShadingMode m) { return m == PT_SHADE_MATERIALS || m == PT_SHADE_MATERIALS_UNIT; }
@@ -194,6 +202,10 @@ struct PtContext {
     int sched_mode = 2;             // 0 raster order, 1 cost-ordered tiles, 2 cost-ordered items with heavy tiles split by samples
     int32_t fail_grid_alloc = 0, grid_allocs = 0;  // PT_FAIL_GRID_ALLOC=k (testing): the k-th allocation of the grid build fails
     bool no_alloc = false;          // inside pt_dispatch_static: whatever would allocate device or host memory fails instead
+    hipEvent_t ev_static = nullptr; // recorded behind the launches of every pt_dispatch_static of this context
+    int fault_inject = 0;           // PT_FAULT_INJECT=grid|bvh (testing pt_verify_accel): the structure is damaged on purpose after it is built
+    unsigned long long* d_verify_out = nullptr;   // three counters of pt_verify_accel
+    uint32_t* d_compact_tmp = nullptr;            // per-workgroup counts of the record compaction
 
     // uniforms
     PtUniforms uniforms{};
@@ -405,6 +417,12 @@ PtStatus build_grid(PtContext* ctx) {
         g.list_capacity = cap;
     }
     PT_HIP_TRY(pt_grid_fill(g, ctx->d_tris, ctx->num_triangles, ctx->stream));
+    if (ctx->fault_inject == 1) {
+        // testing pt_verify_accel: a sixteenth of the rows of cells, through the middle of the +z face, forget their triangles
+        const size_t rows = (size_t)std::max(2, g.res / 16);
+        const size_t first = ((size_t)4 * g.res + (size_t)g.res / 2 - rows / 2) * g.res;
+        PT_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(g.cells + first), (int)PT_GRID_EMPTY, rows * g.res, ctx->stream));
+    }
     {
         // Queries consult the block bits where they can end many of them early: a quarter of the blocks empty, or more.
         // (Cornell, a closed box: none, and the look-up would only lengthen every query.)
@@ -428,6 +446,8 @@ void free_mesh(PtContext* ctx) {
     float** f[] = {&ctx->d_vertices, &ctx->d_tris, &ctx->d_vnormals, &ctx->d_gnormals, &ctx->d_cull, &ctx->d_tris_abs, &ctx->d_tris_live, &ctx->d_tris_grid};
     if (ctx->d_live_count) (void)hipFree(ctx->d_live_count);
     ctx->d_live_count = nullptr;
+    if (ctx->d_compact_tmp) (void)hipFree(ctx->d_compact_tmp);
+    ctx->d_compact_tmp = nullptr;
     for (float** q : f) {
         if (*q) (void)hipFree(*q);
         *q = nullptr;
@@ -476,7 +496,7 @@ PtStatus ensure_records(PtContext* ctx) {
 // compacted record array of the all-triangles loop
 PtStatus ensure_live(PtContext* ctx) {
     if (ctx->live_valid) return PT_OK;
-    PT_HIP_TRY(pt_launch_compact_triangles(ctx->d_tris, ctx->num_triangles, ctx->d_tris_live, ctx->d_live_count, ctx->stream));
+    PT_HIP_TRY(pt_launch_compact_triangles(ctx->d_tris, ctx->num_triangles, ctx->d_tris_live, ctx->d_live_count, ctx->d_compact_tmp, ctx->stream));
     ctx->live_valid = true;
     return PT_OK;
 }
@@ -488,6 +508,13 @@ PtStatus ensure_bvh_emit(PtContext* ctx) {
     // absolute-box variant: its padding scales with the largest coordinate a ray origin or a box can have
     ctx->bvh.scene_scale = std::max(ctx->mesh_extent, std::max(std::fabs(ro[0]), std::max(std::fabs(ro[1]), std::fabs(ro[2]))));
     PT_HIP_TRY(pt_bvh_emit(ctx->bvh, ro, ctx->d_tris, ctx->d_tris_abs, ctx->stream));
+    if (ctx->fault_inject == 2 && ctx->num_triangles >= 2) {
+        // testing pt_verify_accel: the root forgets its first child -- the binary forms take the second child twice, the wide
+        // form gets an unused slot
+        PT_HIP_TRY(hipMemcpyAsync(ctx->bvh.nodes + 12, ctx->bvh.nodes + 13, sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+        PT_HIP_TRY(hipMemcpyAsync(ctx->bvh.nodes_abs + 12, ctx->bvh.nodes_abs + 13, sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+        PT_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ctx->bvh.nodes_w + 3), (int)PT_BVH_NO_CHILD, 1, ctx->stream));
+    }
     ctx->bvh_emit_valid = true;
     return PT_OK;
 }
@@ -722,6 +749,7 @@ PtStatus pt_create(int32_t device, PtContext** out_ctx) {
     if (err == hipSuccess) err = hipMalloc(&ctx->d_sphere_recs, 80 * sizeof(float));
     if (err == hipSuccess) err = hipEventCreate(&ctx->ev_start);
     if (err == hipSuccess) err = hipEventCreate(&ctx->ev_stop);
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&ctx->ev_static, hipEventDisableTiming);
     if (err != hipSuccess) {
         pt_destroy(ctx);
         return fail(PT_ERR_HIP, "context set-up failed: %s", hipGetErrorString(err));
@@ -743,6 +771,7 @@ PtStatus pt_create(int32_t device, PtContext** out_ctx) {
     if (const char* g = getenv("PT_GRID_QUEUE")) ctx->grid_queue_override = atoi(g);
     if (const char* g = getenv("PT_GRID_FINE_AFTER")) ctx->grid_fine_after = atof(g);
     if (const char* g = getenv("PT_FAIL_GRID_ALLOC")) ctx->fail_grid_alloc = atoi(g);
+    if (const char* g = getenv("PT_FAULT_INJECT")) ctx->fault_inject = g[0] == 'g' ? 1 : (g[0] == 'b' ? 2 : 0);
     if (const char* g = getenv("PT_GRID_RES")) ctx->grid_res_override = std::min(atoi(g), 8192);  // cell indices stay far below 2^32
     if (const char* l = getenv("PT_LANE_WALK")) ctx->lane_walk = l[0] == '0' ? 0 : (l[0] == '2' ? 2 : 1);
     if (const char* l = getenv("PT_LANE_STACK_LIMIT")) ctx->lane_stack_limit = std::max(0, std::min(PT_LANE_STACK, atoi(l)));
@@ -756,8 +785,14 @@ PtStatus pt_destroy(PtContext* ctx) {
     if (!ctx) return PT_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->device < kMaxDevices) {  // (the stream is idle: whatever this context left in the GPU's scratch array is no longer in use)
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (g_scratch_use[ctx->device].owner == ctx) g_scratch_use[ctx->device] = ScratchUse{};
+    }
     free_target(ctx);
     free_mesh(ctx);
+    if (ctx->ev_static) (void)hipEventDestroy(ctx->ev_static);
+    if (ctx->d_verify_out) (void)hipFree(ctx->d_verify_out);
     if (ctx->d_spheres) (void)hipFree(ctx->d_spheres);
     if (ctx->d_sphere_recs) (void)hipFree(ctx->d_sphere_recs);
     if (ctx->d_materials) (void)hipFree(ctx->d_materials);
@@ -869,6 +904,7 @@ PtStatus pt_upload_mesh(PtContext* ctx, const float* vertices, int32_t num_verti
     alloc(&ctx->d_tris, (nt + PT_TRI_PAD) * PT_TRI_FLOATS * sizeof(float));
     alloc(&ctx->d_tris_live, (nt + PT_TRI_PAD) * PT_TRI_FLOATS * sizeof(float));
     alloc(&ctx->d_live_count, sizeof(uint32_t));
+    alloc(&ctx->d_compact_tmp, pt_compact_temp_words(num_triangles) * sizeof(uint32_t));
     alloc(&ctx->d_vnormals, nt * 9 * sizeof(float));
     alloc(&ctx->d_gnormals, nt * 3 * sizeof(float));
     alloc(&ctx->d_cull, nt * PT_CULL_FLOATS * sizeof(float));
@@ -1404,35 +1440,65 @@ PtStatus pt_dispatch_static(PtContext* ctx, int32_t first_sample, int32_t num_sa
         ~NoAlloc() { c->no_alloc = false; }
     } guard(ctx);
 
+    // The array belongs to the GPU, not to the context: a call of ANOTHER context whose launches may still be running would
+    // have its work list and parked samples overwritten. Such a call is refused (the same context's calls follow each other
+    // on its stream).
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        ScratchUse& use = g_scratch_use[ctx->device];
+        if (use.owner != nullptr && use.owner != ctx) {
+            const hipError_t q = use.issuing ? hipErrorNotReady : hipEventQuery(use.done);
+            if (q == hipErrorNotReady)
+                return fail(PT_ERR_STATE, "pt_dispatch_static: another context's pt_dispatch_static is still running on device %d, and all "
+                            "contexts of a GPU share one scratch array: wait for it (pt_finish) before this call", ctx->device);
+            if (q != hipSuccess) return fail(PT_ERR_HIP, "hipEventQuery failed: %s", hipGetErrorString(q));
+        }
+        use.owner = ctx;
+        use.done = ctx->ev_static;
+        use.issuing = true;
+    }
+    struct Issued {   // whatever was launched is followed by the event the next caller on this GPU looks at
+        PtContext* c;
+        ~Issued() {
+            (void)hipEventRecord(c->ev_static, c->stream);
+            std::lock_guard<std::mutex> lock(g_scratch_mutex);
+            if (g_scratch_use[c->device].owner == c) g_scratch_use[c->device].issuing = false;
+        }
+    } issued{ctx};
+
     PtKernelParams p;
     const Program* prog = nullptr;
-    // Like a pt_dispatch that has no tile costs to go by, a long range renders its first samples on their own and the
-    // costs they record schedule the rest -- with the launches sized for the largest list the array can hold instead of
-    // the scheduler's counts, which are not read back. Any list that covers every (tile, sample) once renders the image
-    // pt_dispatch renders.
-    const Program* current = find_program(ctx, ctx->current_program);
-    const bool plain = current && current->kind == PT_PROGRAM_CPU_TRACER;   // (no work list: one launch)
-    const int32_t probe = (ctx->sched_mode == 2 && num_samples >= 4 * PT_PROBE_SAMPLES && !plain) ? PT_PROBE_SAMPLES : 0;
-    s = begin_pass(ctx, &p, &prog, first_sample, probe ? probe : num_samples, stride);
+    // Everything that can refuse the call for its state (no program, no uniforms, a direction grid that would need new arrays)
+    // is found out before anything is launched.
+    s = fill_params(ctx, &p, &prog);
     if (s != PT_OK) return s;
     if (ctx->timing) {
         s = collect_timing(ctx);
         if (s != PT_OK) return s;
-        PT_HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
+        PT_HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));   // (before the whole-image copy of a partial window, as in pt_dispatch)
     }
-    if (probe) {
-        // the array keeps what the last call left in it: the costs start at zero
-        PT_HIP_TRY(hipMemsetAsync(cost, 0, tiles * sizeof(uint32_t), ctx->stream));
-        p.tile_cost = cost;
-    }
-    s = end_pass(ctx, p, prog, probe ? probe : num_samples);
-    if (s != PT_OK) return s;
-    if (probe) {
+    // Like a pt_dispatch that has no tile costs to go by, a long range renders its first samples on their own and the
+    // costs they record schedule the rest -- with the launches sized for the largest list the array can hold instead of
+    // the scheduler's counts, which are not read back. Any list that covers every (tile, sample) once renders the image
+    // pt_dispatch renders. Should a HIP call fail after the first launch, the image holds the first PT_PROBE_SAMPLES samples
+    // of the range and PtStats::samples counts them; PtStats::dispatches is only incremented by a call that succeeded.
+    const bool plain = prog->kind == PT_PROGRAM_CPU_TRACER;   // (no work list: one launch)
+    const int32_t probe = (ctx->sched_mode == 2 && num_samples >= 4 * PT_PROBE_SAMPLES && !plain) ? PT_PROBE_SAMPLES : 0;
+    auto launches = [&]() -> PtStatus {
+        PtStatus st = begin_pass(ctx, &p, &prog, first_sample, probe ? probe : num_samples, stride);
+        if (st != PT_OK) return st;
+        if (probe) {
+            // the array keeps what the last call left in it: the costs start at zero
+            PT_HIP_TRY(hipMemsetAsync(cost, 0, tiles * sizeof(uint32_t), ctx->stream));
+            p.tile_cost = cost;
+        }
+        st = end_pass(ctx, p, prog, probe ? probe : num_samples);
+        if (st != PT_OK || !probe) return st;
         const int32_t rest = num_samples - probe;
         const int entry_bytes = is_materials(ctx->shading_mode) && prog->kind != PT_PROGRAM_WORLD ? 16 : 8;
         const size_t slot_bytes = (size_t)rest * PT_TILE_THREADS * (size_t)entry_bytes;
-        s = begin_pass(ctx, &p, &prog, first_sample + probe * stride, rest, stride);
-        if (s != PT_OK) return s;
+        st = begin_pass(ctx, &p, &prog, first_sample + probe * stride, rest, stride);
+        if (st != PT_OK) return st;
         const float factor = ctx->split_factor >= 0.f ? std::min(ctx->split_factor, (float)PT_MAX_SPLIT_FACTOR)
                                                       : ((p.bvh_nodes || p.bvh_nodes_abs) ? 4.0f : kSpreadSplitFactor);
         size_t max_split = std::min<size_t>((size_t)(factor * (float)ctx->wave_slots), PT_STATIC_MAX_SPLIT);
@@ -1446,9 +1512,10 @@ PtStatus pt_dispatch_static(PtContext* ctx, int32_t first_sample, int32_t num_sa
         p.sample_scratch = parked;
         p.max_items = (int32_t)(tiles + max_split);   // upper bounds: blocks beyond the scheduler's counts leave at once
         p.max_split_tiles = (int32_t)max_split;
-        s = end_pass(ctx, p, prog, rest);
-        if (s != PT_OK) return s;
-    }
+        return end_pass(ctx, p, prog, rest);
+    };
+    s = launches();
+    if (s != PT_OK) return s;
     if (ctx->timing) {
         PT_HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
         ctx->ev_pending = true;
@@ -1473,6 +1540,18 @@ PtStatus pt_readback_rgba32f(PtContext* ctx, float* dst) {
     PT_REQUIRE(ctx->d_image[0] != nullptr, PT_ERR_STATE, "no accumulation target");
     const float* img = ctx->d_image[ctx->current ^ 1];
     PT_HIP_TRY(hipMemcpyAsync(dst, img, (size_t)ctx->width * ctx->height * 16, hipMemcpyDeviceToHost, ctx->stream));
+    PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+PtStatus pt_upload_rgba32f(PtContext* ctx, const float* src) {
+    PtStatus s = bind(ctx);
+    if (s != PT_OK) return s;
+    PT_REQUIRE(src != nullptr, PT_ERR_INVALID_ARGUMENT, "src is null");
+    PT_REQUIRE(ctx->d_image[0] != nullptr, PT_ERR_STATE, "no accumulation target");
+    // the image the last pass wrote is the one the next pass reads (PathTracer.cpp:1384,1398)
+    float* img = ctx->d_image[ctx->current ^ 1];
+    PT_HIP_TRY(hipMemcpyAsync(img, src, (size_t)ctx->width * ctx->height * 16, hipMemcpyHostToDevice, ctx->stream));
     PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
     return PT_OK;
 }
@@ -1564,6 +1643,8 @@ PtStatus pt_get_stats(PtContext* ctx, PtStats* out) {
         fprintf(stderr, "[pt phases] hand-out %llu shade %llu walk %llu ticks\n", c[10], c[11], c[12]);
     }
     out->dispatches = ctx->dispatches;
+    out->bvh_sweeps = ctx->bvh_built ? (uint32_t)ctx->bvh_refit_passes : 0u;
+    out->reserved = 0u;
     out->last_dispatch_ms = ctx->last_ms;
     out->total_dispatch_ms = ctx->total_ms;
     return PT_OK;
@@ -1605,15 +1686,14 @@ PtStatus pt_verify_accel(PtContext* ctx, int32_t bounces, uint64_t result[3]) {
     p.sample_stride = 1;
     p.verify_tris = ctx->d_tris;
     p.verify_bounces = bounces;
-    unsigned long long* d = nullptr;
-    PT_HIP_TRY(hipMalloc(&d, 3 * sizeof(unsigned long long)));
+    if (!ctx->d_verify_out) PT_HIP_TRY(hipMalloc(&ctx->d_verify_out, 3 * sizeof(unsigned long long)));
+    unsigned long long* d = ctx->d_verify_out;
     p.verify_out = d;
     hipError_t e = hipMemsetAsync(d, 0, 3 * sizeof(unsigned long long), ctx->stream);
     if (e == hipSuccess) e = pt_launch_verify(p, ctx->stream);
     unsigned long long h[3] = {0, 0, 0};
     if (e == hipSuccess) e = hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d);
     PT_HIP_TRY(e);
     for (int k = 0; k < 3; ++k) result[k] = h[k];
     return PT_OK;

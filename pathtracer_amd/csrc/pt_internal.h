@@ -225,8 +225,10 @@ hipError_t pt_launch_prepare_triangles(const float* vertices, const uint32_t* in
                                        float* tris_abs, float* tris_grid, int write_static, hipStream_t stream);
 // recs (10 x 8 floats) <- the direction-independent terms of the sphere test for ray origin ro
 hipError_t pt_launch_prepare_spheres(const float* spheres, const float ro[3], float* recs, hipStream_t stream);
-// live <- the records of `tris` that any camera ray can hit at all (e2r > 0), order kept, zero padding after; *live_count <- how many
-hipError_t pt_launch_compact_triangles(const float* tris, int32_t num_triangles, float* live, uint32_t* live_count, hipStream_t stream);
+// live <- the records of `tris` that any camera ray can hit at all (e2r > 0), order kept, zero padding after; *live_count <- how many.
+// tmp: pt_compact_temp_words(num_triangles) words of device scratch.
+size_t pt_compact_temp_words(int32_t num_triangles);
+hipError_t pt_launch_compact_triangles(const float* tris, int32_t num_triangles, float* live, uint32_t* live_count, uint32_t* tmp, hipStream_t stream);
 // bad[0..2] += inputs for which the short reciprocal / square root / log2 quotient differ from the IEEE results (see the kernel)
 hipError_t pt_launch_arith_selftest(unsigned long long* bad, hipStream_t stream);
 hipError_t pt_launch_fill_rgba(float* img, size_t num_pixels, float r, float g, float b, float a, hipStream_t stream);

@@ -1895,33 +1895,77 @@ __global__ void pt_prepare_spheres_kernel(const float* __restrict__ spheres, flo
 // dot(e2, cross(ro - a, e1)) fixed per triangle; det >= 1e-4 is positive, so a triangle with e2r <= 0 (the camera is
 // behind its plane, or in it) yields t <= 0 for every ray and fails the shader's `temp > 0.0` (fs:156) always. Such
 // triangles are left out of the array the all-triangles loop walks: same results, fewer tests (closed meshes lose about
-// half their triangles). One workgroup; each thread compacts a contiguous run, so the ascending order is kept.
-__global__ __launch_bounds__(1024) void pt_compact_triangles_kernel(const float4* __restrict__ tris, int n, float4* __restrict__ live,
-                                                                   uint32_t* __restrict__ live_count) {
-    __shared__ uint32_t offset[1024];
-    const int per = (n + 1023) / 1024, begin = min(n, (int)threadIdx.x * per), end = min(n, begin + per);
+// half their triangles). The ascending order is kept (the loop's strict '<' relies on it). Three launches: every workgroup
+// counts the live records of its PT_COMPACT_CHUNK consecutive records; one workgroup turns the counts into offsets; every
+// workgroup copies its live records to where they belong.
+constexpr int PT_COMPACT_THREADS = 256, PT_COMPACT_ROUNDS = 4, PT_COMPACT_CHUNK = PT_COMPACT_THREADS * PT_COMPACT_ROUNDS;
+
+__device__ __forceinline__ bool record_is_live(const float4* __restrict__ tris, int i, int n) {
+    return i < n && tris[4 * (size_t)i + 3].x > 0.0f;
+}
+
+__global__ __launch_bounds__(PT_COMPACT_THREADS) void pt_compact_count_kernel(const float4* __restrict__ tris, int n, uint32_t* __restrict__ block_count) {
+    __shared__ uint32_t wave_total[PT_COMPACT_THREADS / 64];
+    const int base = (int)blockIdx.x * PT_COMPACT_CHUNK;
     uint32_t mine = 0;
-    for (int i = begin; i < end; ++i) mine += tris[4 * (size_t)i + 3].x > 0.0f ? 1u : 0u;
-    offset[threadIdx.x] = mine;
+    for (int r = 0; r < PT_COMPACT_ROUNDS; ++r) mine += record_is_live(tris, base + r * PT_COMPACT_THREADS + (int)threadIdx.x, n) ? 1u : 0u;
+    const uint32_t w = (uint32_t)wave_sum((unsigned long long)mine);
+    if ((threadIdx.x & 63) == 0) wave_total[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) block_count[blockIdx.x] = wave_total[0] + wave_total[1] + wave_total[2] + wave_total[3];
+}
+
+// counts -> exclusive offsets in place; *live_count <- the total; the PT_TRI_PAD all-zero records the loop reads past the end
+__global__ __launch_bounds__(1024) void pt_compact_offsets_kernel(uint32_t* __restrict__ block_count, int blocks, float4* __restrict__ live,
+                                                                 uint32_t* __restrict__ live_count) {
+    __shared__ uint32_t part[1024];
+    // each thread owns a contiguous run of the counts
+    const int per = (blocks + 1023) / 1024, begin = min(blocks, (int)threadIdx.x * per), end = min(blocks, begin + per);
+    uint32_t mine = 0;
+    for (int i = begin; i < end; ++i) mine += block_count[i];
+    part[threadIdx.x] = mine;
     __syncthreads();
     for (int step = 1; step < 1024; step <<= 1) {  // inclusive scan
-        const uint32_t add = threadIdx.x >= (unsigned)step ? offset[threadIdx.x - step] : 0u;
+        const uint32_t add = threadIdx.x >= (unsigned)step ? part[threadIdx.x - step] : 0u;
         __syncthreads();
-        offset[threadIdx.x] += add;
+        part[threadIdx.x] += add;
         __syncthreads();
     }
-    const uint32_t total = offset[1023];
-    uint32_t out = offset[threadIdx.x] - mine;
+    const uint32_t total = part[1023];
+    uint32_t running = part[threadIdx.x] - mine;
     for (int i = begin; i < end; ++i) {
-        if (tris[4 * (size_t)i + 3].x > 0.0f) {
-            for (int q = 0; q < 4; ++q) live[4 * (size_t)out + q] = tris[4 * (size_t)i + q];
-            ++out;
-        }
+        const uint32_t c = block_count[i];
+        block_count[i] = running;
+        running += c;
     }
-    // the loop reads up to PT_TRI_PAD records past the end: all-zero ones (det = 0 fails the cull)
     if (threadIdx.x < PT_TRI_PAD)
         for (int q = 0; q < 4; ++q) live[4 * ((size_t)total + threadIdx.x) + q] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (threadIdx.x == 0) *live_count = total;
+}
+
+__global__ __launch_bounds__(PT_COMPACT_THREADS) void pt_compact_scatter_kernel(const float4* __restrict__ tris, int n, const uint32_t* __restrict__ block_offset,
+                                                                               float4* __restrict__ live) {
+    __shared__ uint32_t wave_total[PT_COMPACT_THREADS / 64];
+    const int base = (int)blockIdx.x * PT_COMPACT_CHUNK;
+    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+    uint32_t out = block_offset[blockIdx.x];
+    for (int r = 0; r < PT_COMPACT_ROUNDS; ++r) {   // a round = 256 consecutive records, one per thread
+        const int i = base + r * PT_COMPACT_THREADS + (int)threadIdx.x;
+        const bool keep = record_is_live(tris, i, n);
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
+        if (lane == 0) wave_total[wave] = (uint32_t)__builtin_popcountll(mask);
+        __syncthreads();
+        uint32_t before = (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+        uint32_t round_total = 0;
+        for (int w = 0; w < PT_COMPACT_THREADS / 64; ++w) {
+            if (w < wave) before += wave_total[w];
+            round_total += wave_total[w];
+        }
+        if (keep)
+            for (int q = 0; q < 4; ++q) live[4 * ((size_t)out + before) + q] = tris[4 * (size_t)i + q];
+        out += round_total;
+        __syncthreads();
+    }
 }
 
 // Present pass: the reference's copy.fs (pow(rgb, 0.454545), copy.fs:18) followed by the float -> 8-bit conversion
@@ -2140,10 +2184,17 @@ hipError_t pt_launch_prepare_spheres(const float* spheres, const float ro[3], fl
     return hipGetLastError();
 }
 
-hipError_t pt_launch_compact_triangles(const float* tris, int32_t num_triangles, float* live, uint32_t* live_count, hipStream_t stream) {
+size_t pt_compact_temp_words(int32_t num_triangles) {
+    return (size_t)(num_triangles > 0 ? (num_triangles + PT_COMPACT_CHUNK - 1) / PT_COMPACT_CHUNK : 0) + 1;
+}
+
+hipError_t pt_launch_compact_triangles(const float* tris, int32_t num_triangles, float* live, uint32_t* live_count, uint32_t* tmp, hipStream_t stream) {
     if (num_triangles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(pt_compact_triangles_kernel, dim3(1), dim3(1024), 0, stream, reinterpret_cast<const float4*>(tris), num_triangles,
-                       reinterpret_cast<float4*>(live), live_count);
+    const int blocks = (num_triangles + PT_COMPACT_CHUNK - 1) / PT_COMPACT_CHUNK;
+    const float4* in = reinterpret_cast<const float4*>(tris);
+    hipLaunchKernelGGL(pt_compact_count_kernel, dim3(blocks), dim3(PT_COMPACT_THREADS), 0, stream, in, num_triangles, tmp);
+    hipLaunchKernelGGL(pt_compact_offsets_kernel, dim3(1), dim3(1024), 0, stream, tmp, blocks, reinterpret_cast<float4*>(live), live_count);
+    hipLaunchKernelGGL(pt_compact_scatter_kernel, dim3(blocks), dim3(PT_COMPACT_THREADS), 0, stream, in, num_triangles, tmp, reinterpret_cast<float4*>(live));
     return hipGetLastError();
 }
 

@@ -1,5 +1,6 @@
 #include "Shader.h"
 
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <iostream>
@@ -11,8 +12,10 @@ char Shader::g_VersionString[16];
 uint32_t Shader::g_VersionStringSize = 0;
 
 namespace {
-PtContext* g_context = nullptr;
-Shader::Stage g_default_kind = Shader::STAGE_PATHTRACE_WORLD;
+// the device context calls are made on: per thread, like a GL context that is current on the calling thread (the reference makes
+// its context current on the main thread, PathTracer.cpp:1095); a host that drives several GPUs uses a thread per context
+thread_local PtContext* g_context = nullptr;
+std::atomic<Shader::Stage> g_default_kind{Shader::STAGE_PATHTRACE_WORLD};
 
 const char* base_name(const char* path) {
     const char* b = path;
@@ -105,7 +108,7 @@ bool Shader::loadFragmentShader(const char* filename) {
         char* text = LoadFileToMemory(filename);
         Stage s = text ? ClassifySource(text) : STAGE_NONE;
         delete[] text;
-        m_FragmentShader = static_cast<uint32_t>(s != STAGE_NONE ? s : g_default_kind);
+        m_FragmentShader = static_cast<uint32_t>(s != STAGE_NONE ? s : g_default_kind.load());
     } else if (strcmp(base, "copy.fs") == 0) {
         m_FragmentShader = STAGE_PRESENT;
     } else if (ends_with(base, ".fs")) {

@@ -11,7 +11,8 @@
 //     device code here.
 //   * getProgram() returns the handle from pt_program_create(); pass it to pt_use_program() where the reference
 //     called glUseProgram().
-// The device context plays the role of the current GL context: set it once with Shader::SetContext().
+// The device context plays the role of the current GL context: set it with Shader::SetContext() on the thread that makes the
+// calls (it is kept per thread, as a GL context is current per thread).
 #pragma once
 
 #include <cstdint>

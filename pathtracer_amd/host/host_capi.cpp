@@ -8,6 +8,7 @@
 #include "RenderLoop.h"
 #include "Scene.h"
 #include "Shader.h"
+#include "Workloads.h"
 
 #define PTH_API extern "C" __attribute__((visibility("default")))
 
@@ -130,6 +131,74 @@ PTH_API void pth_reference_spheres(float* spheres40, float* materials40) {
     memcpy(materials40, s.materials.data(), 160);
 }
 
+// ---- named workloads (Workloads.h) ----------------------------------------------------------------------------------------
+struct PthWorkload {
+    pthost::Workload w;
+};
+
+PTH_API PthWorkload* pth_workload_build(const char* name, const char* assets_dir, int width, int height, char* err, int err_cap) {
+    PthWorkload* h = new PthWorkload();
+    std::string msg;
+    if (!pthost::buildWorkload(name ? name : "", assets_dir ? assets_dir : "", width, height, h->w, &msg)) {
+        copy_text(err, err_cap, msg.empty() ? std::string("cannot build workload") : msg);
+        delete h;
+        return nullptr;
+    }
+    copy_text(err, err_cap, "");
+    return h;
+}
+
+PTH_API void pth_workload_free(PthWorkload* h) { delete h; }
+
+// info7: program kind, width, height, vertices, triangles, material table rows, 1 = vertex normals usable
+PTH_API void pth_workload_info(const PthWorkload* h, int* info7) {
+    const pthost::Workload& w = h->w;
+    info7[0] = w.program_kind; info7[1] = w.width; info7[2] = w.height;
+    info7[3] = (int)w.mesh.vertices.size(); info7[4] = (int)(w.mesh.indices.size() / 3);
+    info7[5] = (int)w.material_table.size(); info7[6] = w.mesh.has_vertex_normals ? 1 : 0;
+}
+
+// Any destination may be NULL. camera12 = position, lowerLeftCorner, horizontal, vertical.
+PTH_API void pth_workload_copy(const PthWorkload* h, float* vertices6, unsigned* indices, int* material_ids, float* table4, float* camera12,
+                               float* spheres40, float* materials40) {
+    const pthost::Workload& w = h->w;
+    if (vertices6 && !w.mesh.vertices.empty()) memcpy(vertices6, w.mesh.vertices.data(), w.mesh.vertices.size() * sizeof(pthost::Vertex));
+    if (indices)
+        for (size_t i = 0; i < w.mesh.indices.size(); ++i) indices[i] = (unsigned)w.mesh.indices[i];
+    if (material_ids && !w.material_ids.empty()) memcpy(material_ids, w.material_ids.data(), w.material_ids.size() * sizeof(int32_t));
+    if (table4 && !w.material_table.empty()) memcpy(table4, w.material_table.data(), w.material_table.size() * sizeof(pthost::Material));
+    if (camera12) {
+        const pthost::Camera& c = w.scene.camera;
+        const pthost::float3* v[4] = {&c.position, &c.lowerLeftCorner, &c.horizontal, &c.vertical};
+        for (int k = 0; k < 4; ++k) { camera12[3 * k] = v[k]->x; camera12[3 * k + 1] = v[k]->y; camera12[3 * k + 2] = v[k]->z; }
+    }
+    if (spheres40) memcpy(spheres40, w.scene.spheres.data(), 160);
+    if (materials40) memcpy(materials40, w.scene.materials.data(), 160);
+}
+
+static pthost::Mesh mesh_from_arrays(const float* vertices6, int nv, const unsigned* indices, int nt) {
+    pthost::Mesh m;
+    m.vertices.resize((size_t)nv);
+    if (nv > 0) memcpy(m.vertices.data(), vertices6, (size_t)nv * sizeof(pthost::Vertex));
+    m.indices.resize((size_t)nt * 3);
+    for (size_t i = 0; i < m.indices.size(); ++i) m.indices[i] = (int)indices[i];
+    return m;
+}
+
+// instances copies of a mesh (pthost::instancedMesh): out_vertices6 holds instances * nv vertices, out_indices instances * nt * 3
+PTH_API void pth_instanced_mesh(const float* vertices6, int nv, const unsigned* indices, int nt, int instances, int columns, double spacing,
+                                double unit, unsigned seed, float* out_vertices6, unsigned* out_indices) {
+    const pthost::Mesh m = pthost::instancedMesh(mesh_from_arrays(vertices6, nv, indices, nt), instances, columns, spacing, unit, seed);
+    memcpy(out_vertices6, m.vertices.data(), m.vertices.size() * sizeof(pthost::Vertex));
+    for (size_t i = 0; i < m.indices.size(); ++i) out_indices[i] = (unsigned)m.indices[i];
+}
+
+// the distorted copy of a mesh's vertices (pthost::distortedCopy); out_vertices6 holds nv vertices
+PTH_API void pth_distorted_copy(const float* vertices6, int nv, double amplitude, const double* offset3, unsigned seed, float* out_vertices6) {
+    const pthost::Mesh m = pthost::distortedCopy(mesh_from_arrays(vertices6, nv, nullptr, 0), amplitude, offset3, seed);
+    memcpy(out_vertices6, m.vertices.data(), m.vertices.size() * sizeof(pthost::Vertex));
+}
+
 PTH_API float pth_parse_float(const char* text, double fallback) { return ptobj::ParseFloatText(text, text + strlen(text), fallback); }
 
 // 0 none, 1 world, 2 mesh, 3 present
@@ -188,6 +257,46 @@ PTH_API int pth_render_ex(const PthRenderOptions* o, float* rgb_sum, unsigned ch
     opt.translate_z = o->translate_z;
     opt.quiet = true;
     return run_loop(opt, rgb_sum, rgba8, stats3, err, err_cap);
+}
+
+// A named workload (Workloads.h) through the render loop, on one GPU (num_devices = 0: device 0) or on several (one rank per
+// entry of `devices`, which may repeat a device; partition 0 = sample, 1 = tile; exchange 0 = auto, 1 = RCCL, 2 = host).
+// shading 0 = reference, 1 = materials. rgb_sum / rgba8 / stats3 as for pth_render; stats3[2] = 1 when RCCL merged the images.
+PTH_API int pth_render_workload(const char* workload, const char* assets_dir, int width, int height, int passes, int samples_per_dispatch,
+                                int shading, const int* devices, int num_devices, int partition, int exchange, int block_rows, int every_frame,
+                                float* rgb_sum, unsigned char* rgba8, double* stats3, char* err, int err_cap) {
+    pthost::RenderOptions opt;
+    opt.workload = workload ? workload : "";
+    opt.assets_dir = assets_dir ? assets_dir : "assets";
+    opt.width = width;
+    opt.height = height;
+    opt.passes = passes;
+    opt.samples_per_dispatch = samples_per_dispatch;
+    opt.shade_materials = shading != 0;
+    opt.quiet = true;
+    Framebuffer fb;
+    pthost::RenderResult res;
+    int rc;
+    if (num_devices <= 0) {
+        rc = pthost::RunRenderLoop(opt, fb, res);
+    } else {
+        pthost::MultiGpuOptions multi;
+        multi.devices.assign(devices, devices + num_devices);
+        multi.partition = partition ? pthost::MultiGpuOptions::TILE : pthost::MultiGpuOptions::SAMPLE;
+        multi.exchange = exchange == 1 ? pthost::MultiGpuOptions::EXCHANGE_RCCL : (exchange == 2 ? pthost::MultiGpuOptions::EXCHANGE_HOST : pthost::MultiGpuOptions::EXCHANGE_AUTO);
+        multi.block_rows = block_rows > 0 ? block_rows : 16;
+        multi.exchange_every_frame = every_frame != 0;
+        rc = pthost::RunRenderLoopMulti(opt, multi, fb, res);
+    }
+    if (rc == 0) {
+        const size_t n = (size_t)res.width * res.height;
+        if (rgb_sum) memcpy(rgb_sum, fb.accumulationBuffer, n * 3 * sizeof(float));
+        if (rgba8) memcpy(rgba8, fb.colorBuffer, n * 4);
+        if (stats3) { stats3[0] = (double)res.rays; stats3[1] = (double)res.samples; stats3[2] = res.exchange == "rccl" ? 1.0 : 0.0; }
+    }
+    copy_text(err, err_cap, res.error);
+    fb.destroy();
+    return rc;
 }
 
 // The whole render loop. rgb_sum (may be NULL) receives Framebuffer::accumulationBuffer (w*h*3), rgba8 (may be NULL)

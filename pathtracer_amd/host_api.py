@@ -172,3 +172,29 @@ def render(obj_path, width, height, passes, samples_per_dispatch=1, program_kind
     if rc != 0:
         raise RuntimeError(err.value.decode(errors="replace"))
     return rgb, rgba8, {"rays": int(stats[0]), "samples": int(stats[1]), "device_ms": float(stats[2])}
+
+
+def render_workload(workload, width=0, height=0, passes=16, samples_per_dispatch=4, shading="reference", devices=(), partition="sample",
+                    exchange="auto", block_rows=16, every_frame=True, assets_dir=None):
+    """A named workload through the C++ render loop: on one GPU (devices empty), or with one rank per entry of `devices`
+    (pthost::RunRenderLoopMulti; a device may repeat = logical ranks, host exchange). Returns (accumulationBuffer [h,w,3] running
+    sums, colorBuffer [h,w,4] uint8, stats). width/height 0 = the workload's own size: pass them when they are not known."""
+    from . import scenes
+    if not width or not height:
+        sc = scenes.SceneData(workload)
+        width, height = sc.width, sc.height
+    L = load()
+    L.pth_render_workload.restype = C.c_int
+    L.pth_render_workload.argtypes = [C.c_char_p, C.c_char_p] + [C.c_int] * 5 + [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 3 + [C.c_char_p, C.c_int]
+    rgb = np.zeros((height, width, 3), np.float32)
+    rgba8 = np.zeros((height, width, 4), np.uint8)
+    stats = np.zeros(3, np.float64)
+    err = C.create_string_buffer(1024)
+    dev = np.asarray(list(devices), np.int32)
+    rc = L.pth_render_workload(workload.encode(), (assets_dir or scenes.ASSETS).encode(), width, height, passes, samples_per_dispatch,
+                               1 if shading == "materials" else 0, dev.ctypes.data if len(dev) else None, len(dev),
+                               1 if partition == "tile" else 0, {"auto": 0, "rccl": 1, "host": 2}[exchange], block_rows, 1 if every_frame else 0,
+                               rgb.ctypes.data, rgba8.ctypes.data, stats.ctypes.data, err, len(err))
+    if rc != 0:
+        raise RuntimeError(err.value.decode(errors="replace"))
+    return rgb, rgba8, {"rays": int(stats[0]), "samples": int(stats[1]), "rccl": bool(stats[2])}

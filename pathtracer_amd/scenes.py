@@ -1,5 +1,6 @@
-"""Named workloads: which OBJ, which camera, which program. Scene data comes from the C++ host library (the same
-code path a C++ host uses); nothing here computes geometry itself."""
+"""Named workloads: which OBJ, which camera, which program, which material table. Everything comes from the C++ host library
+(pathtracer_amd/host/Workloads.cpp -- the code a C++ host and `pt_render --workload` use); nothing here computes geometry."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -9,136 +10,70 @@ from . import capi, host_api
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ASSETS = os.path.join(ROOT, "assets")
 
-# The reference hard-codes eye (0,0,0) looking down +z with a 60 degree vertical field of view and moves the mesh to
-# z+3 (PathTracer.cpp:1160-1162, 1178-1183). That frames the monkey heads; the Cornell box (0..556 units) needs a
-# camera of its own, which is a choice of this build: the classic Cornell view.
-REFERENCE_VIEW = dict(fov=60.0, eye=(0.0, 0.0, 0.0), target=(0.0, 0.0, 1.0), up=(0.0, 1.0, 0.0), translate_z=3.0)
-CORNELL_VIEW = dict(fov=39.3, eye=(278.0, 273.0, -800.0), target=(278.0, 273.0, 0.0), up=(0.0, 1.0, 0.0), translate_z=0.0)
-
-WORKLOADS = {
-    # name: (obj, view, program, default width, height)
-    "cornell": ("cornell_box.obj", CORNELL_VIEW, capi.PROGRAM_MESH, 1920, 1080),
-    "monkeyhead2": ("monkeyhead2.obj", REFERENCE_VIEW, capi.PROGRAM_MESH, 1920, 1080),
-    "suzanne": ("suzanne.obj", REFERENCE_VIEW, capi.PROGRAM_MESH, 1920, 1080),
-    "torus": ("catmark_torus_creases0.obj", REFERENCE_VIEW, capi.PROGRAM_MESH, 3840, 2160),
-    "world": ("monkeyhead2.obj", REFERENCE_VIEW, capi.PROGRAM_WORLD, 1280, 720),
-}
+WORKLOADS = ("cornell", "monkeyhead2", "suzanne", "torus", "world", "instanced", "torus_distorted")
 
 
-def _lcg_uniform(count, seed=20260101):
-    """Deterministic uniform [0,1) stream: 32-bit LCG (Numerical Recipes constants), top 24 bits."""
-    out = np.empty(count, np.float64)
-    state = seed & 0xFFFFFFFF
-    for i in range(count):
-        state = (1664525 * state + 1013904223) & 0xFFFFFFFF
-        out[i] = (state >> 8) / float(1 << 24)
-    return out
+def _lib():
+    L = host_api.load()
+    if not getattr(L, "_workloads_bound", False):
+        L.pth_workload_build.restype = C.c_void_p
+        L.pth_workload_build.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_int]
+        L.pth_workload_free.argtypes = [C.c_void_p]
+        L.pth_workload_info.argtypes = [C.c_void_p, C.c_void_p]
+        L.pth_workload_copy.argtypes = [C.c_void_p] + [C.c_void_p] * 7
+        L.pth_instanced_mesh.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_uint,
+                                         C.c_void_p, C.c_void_p]
+        L.pth_distorted_copy.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_uint, C.c_void_p]
+        L._workloads_bound = True
+    return L
 
 
 def instanced_mesh(vertices, indices, instances=254, columns=16, spacing=2.8, unit=30.0, seed=20260101):
-    """Synthetic large scene: `instances` copies of a mesh on a jittered columns-wide grid facing the camera, each
-    with its own yaw, jitter and depth from a fixed LCG seed, everything scaled to Cornell-like units so that the
-    shader's absolute `det >= 1e-4` cull keeps the small triangles. Returns (vertices6, indices)."""
-    v = np.asarray(vertices, np.float32).reshape(-1, 6)[:, :3].astype(np.float64)
-    idx = np.asarray(indices, np.uint32).reshape(-1, 3)
-    rnd = _lcg_uniform(instances * 4, seed).reshape(instances, 4)
-    rows = (instances + columns - 1) // columns
+    """`instances` jittered copies of a mesh on a grid facing the camera (pthost::instancedMesh). Returns (vertices6, indices)."""
+    v = np.ascontiguousarray(vertices, np.float32).reshape(-1, 6)
+    idx = np.ascontiguousarray(indices, np.uint32).reshape(-1, 3)
     out_v = np.zeros((instances * len(v), 6), np.float32)
     out_i = np.zeros((instances * len(idx), 3), np.uint32)
-    for k in range(instances):
-        cx = (k % columns - (columns - 1) / 2.0) * spacing + (rnd[k, 0] - 0.5) * 0.8
-        cy = (k // columns - (rows - 1) / 2.0) * spacing + (rnd[k, 1] - 0.5) * 0.8
-        cz = (rnd[k, 2] - 0.5) * 6.0
-        yaw = (rnd[k, 3] - 0.5) * 1.0
-        c, s_ = np.cos(yaw), np.sin(yaw)
-        x = v[:, 0] * c + v[:, 2] * s_
-        z = -v[:, 0] * s_ + v[:, 2] * c
-        p = np.stack([x + cx, v[:, 1] + cy, z + cz], 1) * unit
-        out_v[k * len(v):(k + 1) * len(v), :3] = p.astype(np.float32)
-        out_i[k * len(idx):(k + 1) * len(idx)] = idx + np.uint32(k * len(v))
+    _lib().pth_instanced_mesh(v.ctypes.data, len(v), idx.ctypes.data, len(idx), instances, columns, spacing, unit, seed,
+                              out_v.ctypes.data, out_i.ctypes.data)
     return out_v, out_i
 
 
 def distorted_copy(vertices, amplitude=0.12, offset=(0.0, 0.0, 0.0), seed=20260101):
-    """A deterministically distorted copy of a mesh: every vertex moved by up to `amplitude` along each axis with offsets
-    from the fixed LCG stream (integer arithmetic, so the same on every machine), then translated by `offset`. Stands in
-    for the reference's data/distordedmesh/*.bin, a container that nothing in the reference loads. Returns vertices6."""
-    v = np.asarray(vertices, np.float32).reshape(-1, 6).astype(np.float64)
-    rnd = _lcg_uniform(len(v) * 3, seed).reshape(len(v), 3)
+    """A deterministically distorted copy of a mesh's vertices (pthost::distortedCopy). Returns vertices6."""
+    v = np.ascontiguousarray(vertices, np.float32).reshape(-1, 6)
+    off = np.asarray(offset, np.float64)
     out = np.zeros((len(v), 6), np.float32)
-    out[:, :3] = (v[:, :3] + (rnd - 0.5) * (2.0 * amplitude) + np.asarray(offset, np.float64)).astype(np.float32)
+    _lib().pth_distorted_copy(v.ctypes.data, len(v), amplitude, off.ctypes.data, seed, out.ctypes.data)
     return out
-
-
-def torus_with_distorted_copy(vertices, indices, separation=1.4):
-    """The torus moved `separation` to the left, and its distorted copy the same distance to the right: one mesh of twice the
-    triangles (ids of the copy follow those of the original). Edges are about 0.3-1 unit long, far above what the shader's
-    absolute `det >= 1e-4` cull removes."""
-    v = np.asarray(vertices, np.float32).reshape(-1, 6)
-    idx = np.asarray(indices, np.uint32).reshape(-1, 3)
-    left = v.copy()
-    left[:, 0] = (left[:, 0].astype(np.float64) - separation).astype(np.float32)
-    right = distorted_copy(v, offset=(separation, 0.0, 0.0))
-    return np.concatenate([left, right]), np.concatenate([idx, idx + np.uint32(len(v))])
 
 
 class SceneData:
     def __init__(self, name, width=None, height=None):
-        if name == "instanced":
-            self._init_instanced(width, height)
-            return
-        if name == "torus_distorted":
-            self._init_torus_distorted(width, height)
-            return
-        obj, view, program, w0, h0 = WORKLOADS[name]
-        self.name, self.program = name, program
-        self.width, self.height = width or w0, height or h0
-        o = host_api.ObjFile(os.path.join(ASSETS, obj), ASSETS + "/")
-        mesh = o.mesh_default if view["translate_z"] == 3.0 else o.mesh_untranslated
-        self.vertices, self.indices = mesh["vertices"], mesh["indices"]
-        # rows for the diffuse/emissive shading mode: MTL-derived table, "no material" -> its last row
-        self.material_table = o.material_table
-        self.material_ids = np.where(mesh["material_ids"] < 0, len(o.material_table) - 1, mesh["material_ids"]).astype(np.int32)
-        self.normal_mode = capi.NORMALS_VERTEX if mesh["has_vertex_normals"] else capi.NORMALS_GEOMETRIC
-        self.camera = host_api.camera(view["fov"], self.width, self.height, view["eye"], view["target"], view["up"])
-        self.spheres, self.materials = host_api.reference_spheres()
-        self.num_triangles = len(self.indices)
-
-    def _init_instanced(self, width, height):
-        """~1M triangles: 254 copies of suzanne.obj (3936 triangles each = 999,744), geometric normals, camera on the
-        grid's axis far enough to see all of it."""
-        self.name, self.program = "instanced", capi.PROGRAM_MESH
-        self.width, self.height = width or 3840, height or 2160
-        o = host_api.ObjFile(os.path.join(ASSETS, "suzanne.obj"), ASSETS + "/")
-        base = o.mesh_untranslated
-        unit = 30.0
-        self.vertices, self.indices = instanced_mesh(base["vertices"], base["indices"], unit=unit)
-        # diffuse/emissive mode: one colour per instance, every 16th instance a lamp
-        tris_per = len(base["indices"])
-        inst = np.arange(len(self.indices)) // tris_per
-        self.material_ids = (inst % 8).astype(np.int32)
-        self.material_table = np.array([[0.8, 0.8, 0.8, 0], [0.8, 0.3, 0.3, 0], [0.3, 0.8, 0.3, 0], [0.3, 0.3, 0.8, 0],
-                                        [0.8, 0.8, 0.3, 0], [0.3, 0.8, 0.8, 0], [0.8, 0.3, 0.8, 0], [1.0, 0.9, 0.7, 6.0]], np.float32)
-        self.normal_mode = capi.NORMALS_GEOMETRIC
-        self.camera = host_api.camera(60.0, self.width, self.height, (0.0, 0.0, -44.0 * unit), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0))
-        self.spheres, self.materials = host_api.reference_spheres()
-        self.num_triangles = len(self.indices)
-
-    def _init_torus_distorted(self, width, height):
-        """The benchmark's fourth configuration: catmark_torus_creases0.obj next to a distorted copy of itself, 3840x2160, the
-        reference's camera and its z + 3 translation, geometric normals (the file has no vn)."""
-        self.name, self.program = "torus_distorted", capi.PROGRAM_MESH
-        self.width, self.height = width or 3840, height or 2160
-        o = host_api.ObjFile(os.path.join(ASSETS, "catmark_torus_creases0.obj"), ASSETS + "/")
-        base = o.mesh_default
-        self.vertices, self.indices = torus_with_distorted_copy(base["vertices"], base["indices"])
-        self.material_table = np.array([[0.75, 0.75, 0.75, 0], [0.3, 0.6, 0.8, 0]], np.float32)
-        self.material_ids = (np.arange(len(self.indices)) >= len(base["indices"])).astype(np.int32)
-        self.normal_mode = capi.NORMALS_GEOMETRIC
-        v = REFERENCE_VIEW
-        self.camera = host_api.camera(v["fov"], self.width, self.height, v["eye"], v["target"], v["up"])
-        self.spheres, self.materials = host_api.reference_spheres()
-        self.num_triangles = len(self.indices)
+        L = _lib()
+        err = C.create_string_buffer(1024)
+        h = L.pth_workload_build(name.encode(), (ASSETS + "/").encode(), width or 0, height or 0, err, len(err))
+        if not h:
+            raise KeyError(err.value.decode(errors="replace") or name)
+        try:
+            info = (C.c_int * 7)()
+            L.pth_workload_info(h, info)
+            self.name = name
+            self.program, self.width, self.height = info[0], info[1], info[2]
+            nv, nt, rows = info[3], info[4], info[5]
+            self.vertices = np.zeros((nv, 6), np.float32)
+            self.indices = np.zeros((nt, 3), np.uint32)
+            self.material_ids = np.zeros(nt, np.int32)
+            # rows for the diffuse/emissive shading mode: MTL-derived table ("no material" -> its last row), or the workload's own
+            self.material_table = np.zeros((rows, 4), np.float32)
+            self.camera = np.zeros(12, np.float32)
+            self.spheres, self.materials = np.zeros((10, 4), np.float32), np.zeros((10, 4), np.float32)
+            L.pth_workload_copy(h, self.vertices.ctypes.data, self.indices.ctypes.data, self.material_ids.ctypes.data,
+                                self.material_table.ctypes.data, self.camera.ctypes.data, self.spheres.ctypes.data, self.materials.ctypes.data)
+            self.normal_mode = capi.NORMALS_VERTEX if info[6] else capi.NORMALS_GEOMETRIC
+            self.num_triangles = nt
+        finally:
+            L.pth_workload_free(h)
 
     def upload(self, tracer, depth=10, accel=True, shading="reference"):
         """Scene upload + program + uniforms on a Tracer; the target is the caller's business. shading "materials"

@@ -16,6 +16,9 @@ CASES = ["monkey_mesh_128", "monkey_mesh_160x90", "monkey_mesh_1080p_crop", "wor
          # the same mode on the reference's own mesh with its vertex normals (edits/mesh_materials.txt): 968 triangles, so
          # PT_ACCEL_AUTO renders it through the hierarchy
          "monkey_materials_128",
+         # the benchmark's third configuration in that mode: crops of the 1920x1080 frames of monkeyhead2.obj and suzanne.obj on
+         # their silhouettes, and suzanne (3,936 triangles, geometric normals) as a whole small frame
+         "monkey_materials_1080p_crop", "suzanne_materials_1080p_crop", "suzanne_materials_96",
          # the benchmark's fourth configuration: the torus, and the torus next to its deterministically distorted copy
          "torus_geo_128", "torus_distorted_geo_128", "torus_distorted_geo_256x144", "torus_distorted_4k_crop"]
 

@@ -605,10 +605,25 @@ def test_self_check_on_the_full_4k_million_triangle_frame():
         assert c2 == scene.width * scene.height and (bi, bt) == (0, 0)
 
 
-def test_self_check_reports_a_broken_structure():
-    """The check is not vacuous: a direction grid too coarse for its margins cannot happen by construction, so the test breaks
-    the comparison the other way round -- it traces fewer triangles than the structure holds, where the library itself refuses
-    the structure, and checks a moved camera gets a rebuilt grid (a stale one would show up here as mismatches)."""
+def _tracer_with_env(**env):
+    """A context created while the given environment variables are set (pt_create reads its knobs once)."""
+    import os
+    from pathtracer_amd import Tracer
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        return Tracer(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+def test_self_check_follows_a_moving_camera():
+    """A moved camera gets rebuilt records, boxes and grid (stale ones would show up as mismatches): beside, just in front of, and
+    next to the mesh, through every structure."""
     import pt_oracle as po
     from pathtracer_amd import Tracer
     from pathtracer_amd.scenes import SceneData
@@ -617,8 +632,152 @@ def test_self_check_reports_a_broken_structure():
         scene.upload(t)
         t.target_create(320, 180)
         assert _verify(t, 4, 2)[1:] == (0, 0)
-        for eye in ((0.4, 0.2, 0.5), (0.0, 0.0, 2.2), (-1.5, 0.3, 3.0)):     # beside, just in front of, and next to the mesh
+        for eye in ((0.4, 0.2, 0.5), (0.0, 0.0, 2.2), (-1.5, 0.3, 3.0)):
             t.set_uniforms(po.camera(60.0, 320, 180, eye, (0, 0, 3), (0, 1, 0)), scene.num_triangles, 10)
             for accel in (0, 2, 4):
                 c, bi, bt = _verify(t, accel, 2)
                 assert c >= 320 * 180 and (bi, bt) == (0, 0), (eye, accel, c, bi, bt)
+
+
+@pytest.mark.parametrize("workload,size", [("monkeyhead2", (320, 180)), ("suzanne", (320, 180)), ("instanced", (960, 540))])
+def test_self_check_reports_a_broken_structure(workload, size):
+    """The check is not vacuous. PT_FAULT_INJECT damages a structure after it is built -- `grid`: a sixteenth of the rows of cells, through the
+    middle of the +z face, forget their triangles; `bvh`: the root of every form of the hierarchy forgets its first child --
+    and pt_verify_accel must then count queries whose triangle AND distance differ from the loop over all triangles, through the
+    grid, the per-wave walk and the per-lane walk, while the undamaged structures of the same context still count none. The
+    damaged structure also renders a different image than the sound one (the check sees what a dispatch would use)."""
+    from pathtracer_amd import Tracer
+    from pathtracer_amd.scenes import SceneData
+    scene = SceneData(workload, *size)
+    px = scene.width * scene.height
+
+    def images(t, accel, shading):
+        scene.upload(t, shading=shading)
+        t.target_create(scene.width, scene.height)
+        t.set_accel_mode(accel)
+        t.dispatch(1, 2, 1)
+        t.finish()
+        return t.readback().copy()
+
+    with Tracer(0) as t:
+        sound = {(4, "reference"): images(t, 4, "reference"), (2, "reference"): images(t, 2, "reference"),
+                 (2, "materials"): images(t, 2, "materials")}
+    with _tracer_with_env(PT_FAULT_INJECT="grid") as t:
+        broken = images(t, 4, "reference")
+        c, bi, bt = t.verify_accel(1)
+        assert c >= px and 0 < bt <= bi, (c, bi, bt)             # a lost triangle changes the hit, hence id and distance
+        assert bi < c // 2                                        # ... in the damaged rows only
+        assert n_bit_mismatch(broken, sound[(4, "reference")]) > 0
+        assert _verify(t, 2, 1)[1:] == (0, 0)                     # the hierarchy of the same context is sound
+    with _tracer_with_env(PT_FAULT_INJECT="bvh") as t:
+        broken = images(t, 2, "reference")
+        c, bi, bt = t.verify_accel(1)                             # per-wave walk over the binary form
+        assert c >= px and 0 < bt <= bi, (c, bi, bt)
+        assert n_bit_mismatch(broken, sound[(2, "reference")]) > 0
+        assert _verify(t, 4, 1)[1:] == (0, 0)                     # the direction grid of the same context is sound
+        broken = images(t, 2, "materials")
+        c, bi, bt = t.verify_accel(1)                             # per-lane walk over the four-child form
+        assert c >= px and 0 < bt <= bi, (c, bi, bt)
+        assert n_bit_mismatch(broken, sound[(2, "materials")]) > 0
+    with _tracer_with_env(PT_FAULT_INJECT="bvh", PT_LANE_WALK="0") as t:
+        images(t, 2, "materials")
+        c, bi, bt = t.verify_accel(1)                             # per-wave walk over the absolute binary form
+        assert c >= px and bi > 0, (c, bi, bt)
+
+
+def test_hierarchy_over_degenerate_layouts_stays_shallow():
+    """Meshes on which a cost-driven split peels off a sliver per level: thousands of zero-area triangles strung along a line
+    (every candidate plane costs 0, so the first one wins: a sixteenth of the range per level), and centroids in geometric
+    progression. The host builder halves ranges beyond a fixed depth, so the height stays far below the walks' fixed stacks
+    (PtStats::bvh_sweeps bounds it), and a camera at the far end of the string -- for which the deep child is the near one, the
+    worst case for the stack -- gets the same hits as the loop over all triangles, in both shading modes."""
+    from pathtracer_amd import Tracer, capi
+    n_line = 6000
+    x = np.linspace(0.0, 60.0, n_line, dtype=np.float32)
+    line = np.stack([np.stack([x, 0 * x, 0 * x], 1), np.stack([x + 0.004, 0 * x, 0 * x], 1), np.stack([x + 0.008, 0 * x, 0 * x], 1)], 1)
+    k = np.arange(110, dtype=np.float64)
+    gx = (1.0e-4 * 1.18 ** k).astype(np.float32)                       # 1e-4 .. 8e3 in geometric progression
+    geo = np.stack([np.stack([gx, 0 * gx, 0 * gx + 5], 1), np.stack([gx * 1.1, 0 * gx + 1, 0 * gx + 5], 1), np.stack([gx * 1.2, 0 * gx, 0 * gx + 6], 1)], 1)
+    rng = np.random.default_rng(5)
+    real = (rng.uniform(-1.5, 1.5, (300, 1, 3)) + np.array([30.0, 0.0, 0.0]) + rng.uniform(-0.8, 0.8, (300, 3, 3))).astype(np.float32)
+    wall = np.array([[[x0, -25, -25], [x0, -25, 25], [x0, 25, 0]] for x0 in (-2.0, 63.0)] +
+                    [[[x0, -25, -25], [x0, 25, 0], [x0, -25, 25]] for x0 in (-2.0, 63.0)], np.float32)   # both windings, both ends
+    tris = np.concatenate([line, geo.astype(np.float32), real, wall]).astype(np.float32)
+    verts = np.concatenate([tris.reshape(-1, 3), np.zeros((len(tris) * 3, 3), np.float32)], 1)
+    idx = np.arange(len(verts), dtype=np.uint32).reshape(-1, 3)
+    mats = np.zeros((10, 4), np.float32)
+    mats[:, :3] = 0.7
+    mats[1, 3] = 2.0
+    mids = (np.arange(len(idx)) % 2).astype(np.int32)
+    W, H = 96, 64
+    sph, _ = po.reference_spheres_and_materials()
+    with Tracer(0) as t:
+        for eye, target in (((62.0, 0.02, 0.01), (0.0, 0.0, 0.0)), ((-1.0, 0.01, 0.02), (60.0, 0.0, 0.0))):
+            cam = po.camera(50.0, W, H, eye, target, (0.0, 1.0, 0.0))
+            for shading in (0, 1):
+                prog = t.program_create(capi.PROGRAM_MESH)
+                t.use_program(prog)
+                t.upload_spheres(sph)
+                t.upload_materials(mats)
+                t.upload_mesh(verts, idx)
+                t.upload_material_ids(mids)
+                t.set_normal_mode(1)
+                t.set_shading_mode(shading)
+                t.target_create(W, H)
+                t.set_uniforms(cam, len(idx), 10)
+                t.build_accel()
+                sweeps = t.stats()["bvh_sweeps"]
+                assert 8 <= sweeps <= 64, sweeps        # 40 cost-driven levels, then halving: 13 more for 6,400 triangles
+                t.set_accel_mode(capi.ACCEL_BVH)
+                c, bi, bt = t.verify_accel(2)
+                assert c >= W * H and (bi, bt) == (0, 0), (eye, shading, c, bi, bt)
+                t.dispatch(1, 3, 1)
+                t.finish()
+                walked = t.readback().copy()
+                t.set_accel_mode(capi.ACCEL_BRUTE)
+                t.target_clear()
+                t.dispatch(1, 3, 1)
+                t.finish()
+                assert n_bit_mismatch(walked, t.readback()) == 0
+                assert (t.readback_primary()[0] >= 0).sum() > 1000
+                t.set_accel_mode(capi.ACCEL_AUTO)
+                t.program_destroy(prog)
+
+
+@pytest.mark.parametrize("shading", ["reference", "materials"])
+def test_million_triangle_crops_against_the_oracle(shading):
+    """The 999,744-triangle frame of the benchmark's fifth configuration meets the CPU restatement of the shader directly (not
+    only the GPU's own loop): 32x32 crops of the 3840x2160 view on silhouettes of the instances, camera-ray triangles and
+    distances, radiance after 1 and 2 passes and the ray count, bit for bit, in the reference shading (direction grid) and in the
+    diffuse/emissive mode (hierarchy walk per lane); the oracle tests all triangles for every ray (seconds per crop)."""
+    from pathtracer_amd import Tracer
+    from pathtracer_amd.scenes import SceneData
+    sc = SceneData("instanced")
+    mode = 1 if shading == "materials" else 0
+    scene = po.Scene(sc.vertices, sc.indices, sc.spheres, sc.material_table if mode else sc.materials, sc.material_ids if mode else None)
+    u = po.uniforms(sc.camera, sc.width, sc.height, sc.num_triangles, 10, po.VARIANT_MESH, sc.normal_mode, mode)
+    with Tracer(0) as t:
+        sc.upload(t, shading=shading)
+        t.target_create(sc.width, sc.height)
+        for window in [(1932, 1092, 32, 32), (1251, 528, 32, 32), (2440, 1480, 32, 32)]:
+            x0, y0, w, h = window
+            win = (slice(y0, y0 + h), slice(x0, x0 + w))
+            t.set_window(*window)
+            t.target_clear()
+            t.reset_stats()
+            ids, ts = t.readback_primary()
+            oids, ots, _ = po.primary(scene, u, window=window, threads=16)
+            assert np.array_equal(ids[win], oids[win])
+            hit = oids[win] >= 0
+            assert 50 < hit.sum() < w * h, hit.sum()        # a silhouette: hits and sky
+            assert n_bit_mismatch(ts[win][hit], ots[win][hit]) == 0
+            rgba, rays = None, 0
+            for first, count in ((1, 1), (2, 1)):
+                rgba, r = po.render(scene, u, first, count, rgba, window=window, threads=16)
+                rays += r
+                t.dispatch(first, count, 1)
+                t.finish()
+                assert n_bit_mismatch(t.readback()[win], rgba[win]) == 0, (window, first)
+            assert t.stats()["rays"] == rays
+
+

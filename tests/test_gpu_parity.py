@@ -787,6 +787,87 @@ def test_sample_split_over_eight_at_full_size(workload):
         t.close()
 
 
+@pytest.mark.parametrize("name,workload", [("monkey_materials_1080p_crop", "monkeyhead2"), ("suzanne_materials_1080p_crop", "suzanne")])
+def test_config3_in_materials_mode_sample_split_over_eight(name, workload):
+    """Configuration C3 as the benchmark words it -- monkeyhead2.obj / suzanne.obj WITH materials, 1920x1080, 1024 samples, sample
+    split -- through the kernel that mode runs on (hierarchy walk per lane, lanes decoupled). The whole frame after 1 and 4
+    sequential passes holds, in the golden's crop, exactly what the reference shader (with the recorded material edits) rendered
+    there on llvmpipe; the 1024 samples as eight strided residue classes of 128 in running-sum mode (what eight GPUs render), added
+    in fp32 and scaled, equal the sequential running mean to rounding (|difference| < 2e-6 on radiance of order 1); the parts' ray
+    counts add up to the whole's."""
+    from pathtracer_amd import Tracer, capi
+    from pathtracer_amd.scenes import SceneData
+    fx = load_case(name)
+    scene = SceneData(workload)
+    assert (scene.width, scene.height) == (1920, 1080) == (int(fx["width"]), int(fx["height"]))
+    assert n_bit_mismatch(scene.vertices, fx["vertices"]) == 0 and np.array_equal(scene.indices, fx["indices"])
+    assert scene.normal_mode == int(fx["normal_mode"])
+    x0, y0, w, h = (int(v) for v in fx["crop"])
+    with Tracer(0) as t:
+        scene.upload(t, shading="materials")
+        t.upload_materials(fx["materials"])          # the golden's table and per-triangle rows (the files bring no materials)
+        t.upload_material_ids(fx["material_ids"])
+        t.target_create(scene.width, scene.height)
+        t.set_accum_mode(capi.ACCUM_MEAN)
+        done = 0
+        for k in (1, 4):
+            t.dispatch(done + 1, k - done, 1)
+            t.finish()
+            done = k
+            assert n_bit_mismatch(t.readback()[y0:y0 + h, x0:x0 + w, :3], fx[f"lp_rgb_{k}"]) == 0, f"crop after {k} passes"
+        t.dispatch(5, 1020, 1)
+        t.finish()
+        mean = t.readback()[..., :3].copy()
+        st = t.stats()
+        rays = st["rays"]
+        assert st["lane_walk_records"] > 0 and st["samples"] == 1920 * 1080 * 1024   # the decoupled walk rendered it
+        t.reset_stats()
+        t.set_accum_mode(capi.ACCUM_SUM)
+        total = np.zeros_like(mean)
+        for r in range(8):
+            t.target_clear()
+            t.dispatch(1 + r, 128, 8)
+            t.finish()
+            total += t.readback()[..., :3]      # fp32 additions, like the all-reduce
+        assert t.stats()["rays"] == rays
+        scaled = total * np.float32(1.0 / 1024.0)
+        assert np.abs(scaled - mean).max() < 2e-6 * max(1.0, float(mean.max()))
+        # and the merged image still agrees with llvmpipe's 4-pass crop where the two can be compared: the pixels whose every
+        # sample is the same (sky, emitters seen directly) -- the 1024-sample mean of a constant is that constant
+        ref = fx["lp_rgb_4"]
+        const = (fx["lp_rgb_1"] == ref).all(-1) & (fx["lp_id"] < 0)
+        assert const.sum() > 500 and np.abs(scaled[y0:y0 + h, x0:x0 + w][const] - ref[const]).max() < 2e-6
+
+
+def test_resume_from_an_uploaded_image(tracer):
+    """The accumulation image and the sample index are the whole state of a progressive render: passes 1..8, read back, a NEW
+    context, pt_upload_rgba32f, passes 9..16 -- the same bits as passes 1..16 in one go and as llvmpipe's 16-pass image."""
+    from pathtracer_amd import Tracer
+    for name in ("monkey_mesh_128", "cornell_materials_128"):
+        fx = load_case(name)
+        t = tracer
+        prog = setup_case(t, fx)
+        t.dispatch(1, 8, 1)
+        t.finish()
+        saved = t.readback().copy()
+        t.program_destroy(prog)
+        with Tracer(0) as t2:
+            setup_case(t2, fx)
+            t2.upload_image(saved)
+            assert n_bit_mismatch(t2.readback(), saved) == 0
+            t2.dispatch(9, 8, 1)
+            t2.finish()
+            assert n_bit_mismatch(t2.readback()[..., :3], fx["lp_rgb_16"]) == 0
+            # frame by frame from the upload as well (each pass reads the image the one before wrote)
+            t2.upload_image(saved)
+            for s_ in range(9, 17):
+                t2.dispatch(s_, 1, 1)
+            t2.finish()
+            assert n_bit_mismatch(t2.readback()[..., :3], fx["lp_rgb_16"]) == 0
+            with pytest.raises(ValueError):
+                t2.upload_image(saved[:-1])
+
+
 def test_c5_at_its_full_length():
     """Configuration C5 at its own size and length: the ~1M-triangle instanced scene at 3840x2160 with 4096 samples. One dispatch
     of 4096 (probe, work list, split tiles, fold) against sixteen dispatches of 256: the same image bit for bit and the same ray

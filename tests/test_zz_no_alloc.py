@@ -168,3 +168,36 @@ def test_static_dispatch_rejects_windows_beyond_its_array():
         want, got = _both(t, 1, 2)
         assert n_bit_mismatch(got, want) == 0
         t.program_destroy(prog)
+
+
+def test_static_dispatch_refuses_to_share_its_array_with_a_running_call():
+    """All contexts of a GPU share the scratch array: while one context's pt_dispatch_static is still running, another
+    context's call is refused with PT_ERR_STATE and renders nothing; once the first has finished the second goes through and
+    both images equal pt_dispatch's."""
+    import pt_oracle as po
+    from pathtracer_amd import PtError, Tracer
+    fx = load_case("cornell_geo_128")
+    ntri = len(fx["indices"])
+    W, H = 1920, 1080
+    cam = po.camera(39.3, W, H, (278, 273, -800), (278, 273, 0), (0, 1, 0))
+    with Tracer(0) as a, Tracer(0) as b:
+        for t in (a, b):
+            _setup(t, fx, W, H)
+            t.set_uniforms(cam, ntri, 10)
+        a.dispatch(1, 512, 1)
+        a.finish()
+        want = a.readback().copy()
+        a.target_clear()
+        a.finish()
+        a.dispatch_static(1, 512, 1)              # tens of milliseconds of device time, issued asynchronously
+        with pytest.raises(PtError) as err:
+            b.dispatch_static(1, 8, 1)
+        assert err.value.status == 3 and "another context" in str(err.value)
+        assert b.stats()["dispatches"] == 0 and np.all(b.readback()[..., :3] == 0)
+        a.finish()
+        assert n_bit_mismatch(a.readback(), want) == 0
+        b.dispatch_static(1, 512, 1)              # the array is free again
+        b.finish()
+        assert n_bit_mismatch(b.readback(), want) == 0
+        a.dispatch_static(513, 8, 1)              # ... and back
+        a.finish()
