@@ -291,21 +291,27 @@ def config3_materials_cases():
     """The benchmark's third configuration in the diffuse/emissive mode: monkeyhead2.obj and suzanne.obj at 1920x1080 (64x64 crops
     on their silhouettes) and suzanne as a whole small frame. Neither file brings materials (monkeyhead2.mtl is empty, suzanne's
     monkey.mtl is not in the reference), so the MTL rule gives every triangle the grey row; as in monkey_materials_128 three more
-    rows (two albedos and an emitter) are dealt to the triangles by index so that every branch of the mode runs. suzanne.obj has
-    more normals than positions (the reference's pairing of the two does not apply): geometric normals."""
+    rows (two albedos and an emitter) are dealt to the triangles by index so that every branch of the mode runs."""
     sph, _ = po.reference_spheres_and_materials()
     ref_cam = lambda W, H: po.camera(60.0, W, H, (0, 0, 0), (0, 0, 1), (0, 1, 0))
     out = []
-    for obj, nm in (("monkeyhead2", po.NORMALS_VERTEX), ("suzanne", po.NORMALS_GEOMETRIC)):
+    for obj in ("monkeyhead2", "suzanne"):
         d, _ = run_obj_dump(obj)
-        v, i = po.mesh_from_obj_arrays(d["v"], d["idx_v"], d["vn"] if nm == po.NORMALS_VERTEX else None)
+        # the reference's own pairing: normals read with the position index (PathTracer.cpp:1191-1193); both files carry at least as
+        # many vn as v, so the read stays inside the array (for suzanne.obj, 3,936 per-face normals for 2,012 positions, the pairs
+        # are not the file's -- that is what the reference would shade with)
+        v, i = po.mesh_from_obj_arrays(d["v"], d["idx_v"], d["vn"])
         t = np.arange(len(i))
-        scene = po.Scene(v, i, sph, MONKEY_TABLE, np.where(t % 11 == 5, 3, t % 3).astype(np.int32))
+        ids = np.where(t % 11 == 5, 3, t % 3).astype(np.int32)
+        scene = po.Scene(v, i, sph, MONKEY_TABLE, ids)
         short = "monkey" if obj == "monkeyhead2" else obj
-        out.append((f"{short}_materials_1080p_crop", scene, ref_cam(1920, 1080), 1920, 1080, po.VARIANT_MESH, nm, [1, 4],
+        out.append((f"{short}_materials_1080p_crop", scene, ref_cam(1920, 1080), 1920, 1080, po.VARIANT_MESH, po.NORMALS_VERTEX, [1, 4],
                     (1130, 700, 64, 64) if obj == "monkeyhead2" else (1270, 540, 64, 64)))
         if obj == "suzanne":
-            out.append(("suzanne_materials_96", scene, ref_cam(96, 96), 96, 96, po.VARIANT_MESH, nm, [1, 2], None))
+            # ... and the whole head small, with geometric normals (the defined rule for files whose normals do not pair up)
+            vg, ig = po.mesh_from_obj_arrays(d["v"], d["idx_v"], None)
+            out.append(("suzanne_materials_96", po.Scene(vg, ig, sph, MONKEY_TABLE, ids), ref_cam(96, 96), 96, 96, po.VARIANT_MESH,
+                        po.NORMALS_GEOMETRIC, [1, 2], None))
     return out
 
 

@@ -97,6 +97,16 @@ def build_all(force=False):
     return [build_hip(force), build_host(force), build_cli(force)]
 
 
+def build_sanitize():
+    """The host's scene code and the parity oracle in one executable under AddressSanitizer + UndefinedBehaviorSanitizer (host
+    compiler only: oracle/Makefile target `asan`, run by tests/test_sanitizers.py)."""
+    _run(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "asan"])
+    return os.path.join(ROOT, "oracle", "_build", "sanitize_check")
+
+
 if __name__ == "__main__":
+    if "--sanitize" in sys.argv:
+        print(build_sanitize())
+        sys.exit(0)
     for p in build_all(force="--force" in sys.argv):
         print(p)

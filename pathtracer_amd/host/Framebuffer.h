@@ -9,7 +9,9 @@
 #include <cstdint>
 #include <cstring>
 
-inline float saturate(float f) { return f < 0.f ? 0.f : (f > 1.f ? 1.f : f); }
+// clamp to [0, 1]; a NaN becomes 0 (the reference's form, f < 0 ? 0 : (f > 1 ? 1 : f), hands a NaN on to a float -> uint8
+// conversion, which is undefined)
+inline float saturate(float f) { return !(f > 0.f) ? 0.f : (f > 1.f ? 1.f : f); }
 
 struct Color {
     uint8_t R, G, B, A;

@@ -285,7 +285,9 @@ float ParseFloatText(const char* s, const char* end, double fallback) {
             return static_cast<float>(fallback);
         }
         int nexp = 0;
-        while (p != end && is_digit(*p)) { exponent = exponent * 10 + (*p - '0'); ++p; ++nexp; }
+        // (an exponent beyond a few hundred already gives infinity or zero: further digits are read but no longer accumulated,
+        // so that an endless run of them cannot overflow the int)
+        while (p != end && is_digit(*p)) { if (exponent < 100000) exponent = exponent * 10 + (*p - '0'); ++p; ++nexp; }
         exponent *= esign;
         if (nexp == 0) return static_cast<float>(fallback);
     }
