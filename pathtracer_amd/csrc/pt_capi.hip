@@ -198,6 +198,9 @@ struct PtContext {
         int32_t num_triangles, win[4], rows[3], normal_mode, accel_mode;
         uint32_t program;
     } primary_cache_key{};
+    int xcd_groups = 0;             // PT_XCD_GROUPS=1: the work list of multi-sample dispatches is dealt to the XCDs in image bands of
+                                    // equal cost (an experiment that is kept: see kXcdGroups)
+    int list_groups = 1;            // what the list in use was built with
     int sched_sort = 1;             // PT_SCHED_SORT=0: the work list keeps its split but is not ordered by cost
     int sched_mode = 2;             // 0 raster order, 1 cost-ordered tiles, 2 cost-ordered items with heavy tiles split by samples
     int32_t fail_grid_alloc = 0, grid_allocs = 0;  // PT_FAIL_GRID_ALLOC=k (testing): the k-th allocation of the grid build fails
@@ -226,6 +229,11 @@ namespace {
 
 constexpr size_t kCounterBytes = (size_t)PT_COUNTER_SLOTS * PT_COUNTER_STRIDE * sizeof(unsigned long long);
 constexpr int PT_MAX_SPLIT_FACTOR = 8;  // arrays of the scheduler are sized for this many split tiles per wave slot
+constexpr size_t kXcdGroups = 8;        // XCDs of the device: blocks go to them round-robin by block index
+// PT_XCD_GROUPS=1 (off by default) deals the work list to the XCDs in image bands of equal cost, so that every XCD keeps reading
+// the records of one part of the scene. Measured on the 1M-triangle scene, materials mode, 16 samples at 4K: L2 hit rate 0.57 ->
+// 0.75 (129 M -> 74 M misses per dispatch) and the same 8.40 ms -- the per-lane walk is not bound by where its records come
+// from -- while scenes that live in every L2 anyway lose 3-9 % to the coarser balance (36 triangles: 7.06 -> 7.70 ms).
 // Split factor of throughput-bound kernels (loop, direction grid, per-lane walk) on a view whose work is spread out: a tile is
 // split when its cost exceeds total / (factor x wave slots). Slightly below 1 (the kernels hold seven waves per SIMD where the
 // slots count eight, and the list starts the expensive tiles first, so a tile a little above a slot's share still ends
@@ -763,6 +771,7 @@ PtStatus pt_create(int32_t device, PtContext** out_ctx) {
     ctx->wave_slots = prop.multiProcessorCount * 4 * 8;
 
     if (const char* g = getenv("PT_SCHED_SORT")) ctx->sched_sort = atoi(g);
+    if (const char* g = getenv("PT_XCD_GROUPS")) ctx->xcd_groups = atoi(g) != 0;
     if (const char* g = getenv("PT_AUTO_GRID")) ctx->auto_grid = g[0] != '0';
     if (const char* g = getenv("PT_BVH_BUILDER")) ctx->bvh_builder = g[0] == 'm' ? PT_BVH_BUILDER_MORTON : PT_BVH_BUILDER_SAH;
     if (const char* g = getenv("PT_CAMERA_RAY_GRID")) ctx->camera_ray_grid = g[0] != '0';
@@ -1068,7 +1077,8 @@ static PtStatus target_common(PtContext* ctx, int32_t width, int32_t height) {
     PT_HIP_TRY(hipMalloc(&ctx->d_t, n * sizeof(float)));
     const size_t tiles = (size_t)PT_TILES_ACROSS(width) * PT_TILES_ACROSS(height);
     PT_HIP_TRY(hipMalloc(&ctx->d_tile_cost, tiles * sizeof(uint32_t)));
-    PT_HIP_TRY(hipMalloc(&ctx->d_items, (tiles + (size_t)PT_MAX_SPLIT_FACTOR * ctx->wave_slots) * sizeof(PtWorkItem)));
+    // (eight times the items: a list dealt to the XCDs leaves gaps where a band has fewer items than the longest one)
+    PT_HIP_TRY(hipMalloc(&ctx->d_items, kXcdGroups * (tiles + (size_t)PT_MAX_SPLIT_FACTOR * ctx->wave_slots) * sizeof(PtWorkItem)));
     PT_HIP_TRY(hipMalloc(&ctx->d_sched_counts, 2 * sizeof(uint32_t)));
     PT_HIP_TRY(hipMalloc(&ctx->d_sched_tmp, PT_SCHED_TMP_WORDS * sizeof(uint32_t)));
     PT_HIP_TRY(hipMalloc(&ctx->d_split_tiles, (size_t)PT_MAX_SPLIT_FACTOR * ctx->wave_slots * sizeof(uint32_t)));
@@ -1236,7 +1246,8 @@ PtStatus dispatch_range(PtContext* ctx, int32_t first_sample, int32_t num_sample
             const bool splitting = ctx->sched_mode == 2 && num_samples > 1;
             const int entry_bytes = is_materials(ctx->shading_mode) && prog->kind != PT_PROGRAM_WORLD ? 16 : 8;  // what a parked sample takes
             const size_t slot_bytes = (size_t)num_samples * PT_TILE_THREADS * (size_t)entry_bytes;
-            const bool reuse = ctx->list_valid && ctx->list_samples == num_samples && ctx->list_base_factor == base_factor &&
+            const int groups = splitting && prog->kind == PT_PROGRAM_MESH && ctx->xcd_groups != 0 ? (int)kXcdGroups : 1;
+            const bool reuse = ctx->list_valid && ctx->list_samples == num_samples && ctx->list_base_factor == base_factor && ctx->list_groups == groups &&
                                ctx->list_entry_bytes == entry_bytes && ctx->list_age < 16 && ctx->cost_samples < 2 * ctx->list_basis;
             if (!reuse) {
                 // (direction grid: whether its queries look at the block bits first follows the view's statistics so far)
@@ -1249,7 +1260,7 @@ PtStatus dispatch_range(PtContext* ctx, int32_t first_sample, int32_t num_sample
                 for (;;) {
                     const int max_split = splitting ? (int)(factor * (float)ctx->wave_slots) : 0;
                     PT_HIP_TRY(pt_launch_schedule_items(ctx->d_tile_cost, ctx->d_items, ctx->d_sched_counts, ctx->d_split_tiles, ctx->d_sched_tmp, tiles,
-                                                        num_samples, max_split, ctx->sched_sort, ctx->stream));
+                                                        num_samples, max_split, ctx->sched_sort, groups, ctx->stream));
                     if (!splitting) {  // single-sample dispatches (frame loops): whole tiles in cost order, nothing to read back
                         c[0] = (uint32_t)tiles; c[1] = 0;
                         break;
@@ -1257,8 +1268,8 @@ PtStatus dispatch_range(PtContext* ctx, int32_t first_sample, int32_t num_sample
                     PT_HIP_TRY(hipMemcpyAsync(c, ctx->d_sched_counts, sizeof c, hipMemcpyDeviceToHost, ctx->stream));
                     PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
                     if (getenv("PT_DEBUG_SCHED"))
-                        fprintf(stderr, "[pt sched] %d tiles, %d samples, costs from %lld samples, factor %g: %u items, %u split tiles\n", tiles,
-                                num_samples, (long long)ctx->cost_samples, (double)factor, c[0], c[1]);
+                        fprintf(stderr, "[pt sched] %d tiles, %d samples, costs from %lld samples, factor %g, %d group(s): %u list positions, %u split tiles\n", tiles,
+                                num_samples, (long long)ctx->cost_samples, (double)factor, groups, c[0], c[1]);
                     if (ctx->split_factor < 0.f && factor == kSpreadSplitFactor && c[1] >= (uint32_t)(ctx->wave_slots / 5)) {
                         factor = eager_factor;  // work concentrated in few tiles
                         ctx->concentrated = true;
@@ -1286,6 +1297,7 @@ PtStatus dispatch_range(PtContext* ctx, int32_t first_sample, int32_t num_sample
                 ctx->list_samples = num_samples;
                 ctx->list_base_factor = base_factor;
                 ctx->list_entry_bytes = entry_bytes;
+                ctx->list_groups = groups;
                 ctx->list_items = (int)c[0];
                 ctx->list_split = (int)c[1];
                 ctx->list_age = 0;
@@ -1505,7 +1517,7 @@ PtStatus pt_dispatch_static(PtContext* ctx, int32_t first_sample, int32_t num_sa
         max_split = std::min(max_split, kStaticSampleBytes / slot_bytes);  // as many split tiles as the array can park
         if (p.grid_occ && ctx->grid_occ_override < 0)
             PT_HIP_TRY(pt_launch_grid_occ_flag(ctx->d_counters, (unsigned long long)ctx->samples, ctx->d_grid_occ_flag, ctx->stream));
-        PT_HIP_TRY(pt_launch_schedule_items(cost, items, counts, split_tiles, tmp, (int)tiles, rest, (int)max_split, ctx->sched_sort, ctx->stream));
+        PT_HIP_TRY(pt_launch_schedule_items(cost, items, counts, split_tiles, tmp, (int)tiles, rest, (int)max_split, ctx->sched_sort, 1, ctx->stream));
         p.items = items;
         p.sched_counts = counts;
         p.split_tiles = split_tiles;

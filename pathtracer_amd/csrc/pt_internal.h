@@ -149,6 +149,7 @@ hipError_t pt_bvh_emit(const PtBvhBuild& b, const float ro[3], const float* tris
 // One block's work: `sample_count` consecutive samples (from the dispatch's sample_begin-th on) of one tile. A tile
 // with scratch_slot < 0 has a single item that folds its samples into the image itself; the items of a split tile write
 // their samples to the scratch slot and a second kernel folds them in sample order.
+#define PT_NO_TILE 0xffffffffu  // PtWorkItem::tile of a list position that holds no work
 struct PtWorkItem {
     uint32_t tile;
     uint32_t sample_begin;
@@ -236,12 +237,15 @@ hipError_t pt_launch_render(const PtKernelParams& p, int program_kind, hipStream
 hipError_t pt_launch_present(const float* img, size_t num_pixels, uint32_t* out_rgba8, hipStream_t stream);
 // Work list for the next dispatch from the per-tile costs of the previous one: tiles whose cost exceeds
 // total / max_split_tiles are split into several items (at most num_samples), items ordered most expensive first.
-// Always: item count <= num_tiles + max_split_tiles and split tiles <= max_split_tiles. tile_cost is only read.
-// sort = 0 keeps the split but leaves the list in tile order.
-// sched_counts <- {items, split tiles}.
+// Always: items <= num_tiles + max_split_tiles and split tiles <= max_split_tiles. tile_cost is only read.
+// sort = 0 keeps the split but leaves the list in tile order. groups = 1: one list. groups = 8: the tiles are cut into eight
+// runs of equal cost (bands of the image) and run g's items stand at the list positions g, g + 8, ... -- the blocks one XCD
+// takes -- with PT_NO_TILE entries where a run is shorter than the longest; the list then has 8 x the longest run's items
+// positions (at most 8 x (num_tiles + max_split_tiles)).
+// sched_counts <- {list positions, split tiles}.
 hipError_t pt_launch_schedule_items(const uint32_t* tile_cost, PtWorkItem* items, uint32_t* sched_counts, uint32_t* split_tiles, uint32_t* sched_tmp,
-                                    int num_tiles, int num_samples, int max_split_tiles, int sort, hipStream_t stream);
-#define PT_SCHED_TMP_WORDS (4 + 64 * 64)  // scratch of the scheduler's launches: total cost, per-workgroup bucket counts
+                                    int num_tiles, int num_samples, int max_split_tiles, int sort, int groups, hipStream_t stream);
+#define PT_SCHED_TMP_WORDS (16 + 2 * 64 + 64 * 8 * 64)  // scratch of the scheduler's launches: totals, per-workgroup share costs and bucket counts
 // *flag <- whether the direction grid's queries should consult the block bits, from the statistics counters (see the kernel)
 hipError_t pt_launch_grid_occ_flag(const unsigned long long* counters, unsigned long long samples, uint32_t* flag, hipStream_t stream);
 hipError_t pt_launch_primary(const PtKernelParams& p, int program_kind, hipStream_t stream);

@@ -848,6 +848,20 @@ __device__ __forceinline__ unsigned __reduce_max_trips(unsigned v) {
 __device__ __forceinline__ void park(float2* e, float, float, float, float energy, float rdy) { *e = make_float2(energy, rdy); }
 __device__ __forceinline__ void park(float4* e, float sr, float sg, float sb, float, float) { *e = make_float4(sr, sg, sb, 0.f); }
 
+// Which entry of the work list a block takes. Blocks are handed to the eight XCDs (each with its own L2) round-robin by block index.
+__device__ __forceinline__ bool work_item_index(const PtKernelParams& p, unsigned& index) {
+    const unsigned n = *(const kuint32*)p.sched_counts;
+#ifdef PT_V_XCD_BANDS
+    // experiment: XCD x takes the x-th contiguous eighth of the list
+    const unsigned per = (n + 7u) / 8u, j = blockIdx.x >> 3;
+    index = (blockIdx.x & 7u) * per + j;
+    return j < per && index < n;
+#else
+    index = blockIdx.x;
+    return index < n;
+#endif
+}
+
 // KIND: 0 sphere scene, 1 all-triangles loop, 2 LBVH, 3 culled loop. MATERIALS: false = the reference's shading (Phong
 // lobe, grey throughput, origin fixed at the camera), true = the diffuse/emissive mode (coloured throughput, emitted
 // radiance, origin moves to each hit point, so the ray-origin-specific triangle records cannot be used).
@@ -862,8 +876,10 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
     int x, y;
     int tile = (int)blockIdx.x, sample_begin = 0, sample_count = p.num_samples, scratch_slot = -1;
     if (p.items) {
-        if (blockIdx.x >= *(const kuint32*)p.sched_counts) return;  // the grid is sized for the largest possible list
-        const kuint32* item = (const kuint32*)(p.items + blockIdx.x);
+        unsigned index;
+        if (!work_item_index(p, index)) return;  // the grid is sized for the largest possible list
+        const kuint32* item = (const kuint32*)(p.items + index);
+        if (item[0] == PT_NO_TILE) return;  // a position past the end of its group's part of the list
         tile = (int)item[0]; sample_begin = (int)item[1]; sample_count = (int)item[2]; scratch_slot = (int)item[3];
     }
     const bool in_window = pixel_of_lane(p, tile, x, y);
@@ -1290,8 +1306,10 @@ __global__ __launch_bounds__(64, PT_DECOUPLED_MIN_WAVES) void pt_render_decouple
     int x, y;
     int tile = (int)blockIdx.x, sample_begin = 0, sample_count = p.num_samples, scratch_slot = -1;
     if (p.items) {
-        if (blockIdx.x >= *(const kuint32*)p.sched_counts) return;
-        const kuint32* item = (const kuint32*)(p.items + blockIdx.x);
+        unsigned index;
+        if (!work_item_index(p, index)) return;
+        const kuint32* item = (const kuint32*)(p.items + index);
+        if (item[0] == PT_NO_TILE) return;  // a position past the end of its group's part of the list
         tile = (int)item[0]; sample_begin = (int)item[1]; sample_count = (int)item[2]; scratch_slot = (int)item[3];
     }
     const bool in_window = pixel_of_lane(p, tile, x, y);
@@ -2084,73 +2102,157 @@ __device__ __forceinline__ unsigned long long sched_granule(const uint32_t* tmp,
 // the tiles of workgroup b: one contiguous share
 __device__ __forceinline__ void sched_share(int n, int& begin, int& end) {
     const int per = (n + PT_SCHED_BLOCKS - 1) / PT_SCHED_BLOCKS;
-    begin = (int)blockIdx.x * per;
+    begin = min(n, (int)blockIdx.x * per);
     end = begin + per < n ? begin + per : n;
 }
+// Groups: with `groups` = 8 the list is dealt to the eight XCDs of the device. Workgroups go to the XCDs round-robin by block
+// index, every XCD has an L2 of its own, and the records a tile's rays fetch are those of its part of the scene: so the
+// tiles are cut, in raster order, into `groups` runs of equal cost (image bands), group g's items stand at the list positions
+// g, g + groups, g + 2 groups, ... (most expensive first within the group), and the XCD that takes those blocks keeps reading
+// the same part of the scene. Groups differ in length; the unused positions of the shorter ones hold PT_NO_TILE.
+// tmp: [0..1] total cost (64 bit), [2] items of the longest group, [4 + g] items of group g, [16 + 2 w] cost of workgroup w's
+// share of the tiles (64 bit), [PT_SCHED_COUNTS + ((w * 8 + g) * 64 + bucket)] that workgroup's count, then start, in the bucket.
+constexpr int PT_SCHED_SHARES = 16, PT_SCHED_COUNTS = PT_SCHED_SHARES + 2 * PT_SCHED_BLOCKS, PT_SCHED_MAX_GROUPS = 8;
+static_assert(PT_SCHED_COUNTS + PT_SCHED_BLOCKS * PT_SCHED_MAX_GROUPS * 64 == PT_SCHED_TMP_WORDS, "scratch of the scheduler");
 
+__device__ __forceinline__ int sched_counter(int wg, int group, int bucket) { return PT_SCHED_COUNTS + ((wg * PT_SCHED_MAX_GROUPS + group) * 64 + bucket); }
+
+// Exclusive prefix sum of `v` over the workgroup's PT_SCHED_THREADS threads (all of them call); total <- the sum.
+__device__ __forceinline__ unsigned long long sched_block_scan(unsigned long long v, unsigned long long* wave_total, unsigned long long& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    __syncthreads();   // (the previous call's totals have been read)
+    if (lane == 63) wave_total[wave] = incl;
+    __syncthreads();
+    unsigned long long before = 0;
+    total = 0;
+    for (int w = 0; w < PT_SCHED_THREADS / 64; ++w) {
+        if (w < wave) before += wave_total[w];
+        total += wave_total[w];
+    }
+    return before + incl - v;
+}
+
+// Calls body(tile, cost, group) for every tile of this workgroup's share, in chunks of PT_SCHED_THREADS consecutive tiles.
+template <typename Body>
+__device__ __forceinline__ void sched_for_tiles(const uint32_t* __restrict__ cost, int n, int groups, const uint32_t* __restrict__ tmp, Body body) {
+    __shared__ unsigned long long wave_total[PT_SCHED_THREADS / 64];
+    int begin, end;
+    sched_share(n, begin, end);
+    const unsigned long long total = *reinterpret_cast<const unsigned long long*>(tmp);
+    unsigned long long running = 0;
+    if (groups > 1)
+        for (int w = 0; w < (int)blockIdx.x; ++w) running += *reinterpret_cast<const unsigned long long*>(tmp + PT_SCHED_SHARES + 2 * w);
+    for (int base = begin; base < end; base += PT_SCHED_THREADS) {
+        const int i = base + (int)threadIdx.x;
+        const uint32_t c = i < end ? cost[i] : 0u;
+        int group = 0;
+        if (groups > 1) {   // (uniform)
+            unsigned long long chunk;
+            const unsigned long long before = running + sched_block_scan(c, wave_total, chunk);
+            running += chunk;
+            group = total ? (int)min((unsigned long long)(groups - 1), before * (unsigned long long)groups / total) : 0;
+        }
+        if (i < end) body(i, c, group);
+    }
+}
+
+// total cost, and the cost of every workgroup's share
 __global__ __launch_bounds__(PT_SCHED_THREADS) void pt_sched_total_kernel(const uint32_t* __restrict__ cost, int n, uint32_t* __restrict__ tmp) {
+    __shared__ unsigned long long part[PT_SCHED_THREADS / 64];
+    int begin, end;
+    sched_share(n, begin, end);
     unsigned long long mine = 0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) mine += cost[i];
-    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
-    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(reinterpret_cast<unsigned long long*>(tmp), mine);
+    for (int i = begin + (int)threadIdx.x; i < end; i += PT_SCHED_THREADS) mine += cost[i];
+    mine = wave_sum(mine);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long share = 0;
+        for (int w = 0; w < PT_SCHED_THREADS / 64; ++w) share += part[w];
+        *reinterpret_cast<unsigned long long*>(tmp + PT_SCHED_SHARES + 2 * blockIdx.x) = share;
+        if (share) atomicAdd(reinterpret_cast<unsigned long long*>(tmp), share);
+    }
 }
 
 __global__ __launch_bounds__(PT_SCHED_THREADS) void pt_sched_count_kernel(const uint32_t* __restrict__ cost, int n, int num_samples, int max_split,
-                                                                          int sort, uint32_t* __restrict__ tmp) {
-    __shared__ uint32_t hist[64];
-    if (threadIdx.x < 64) hist[threadIdx.x] = 0;
+                                                                          int sort, int groups, uint32_t* __restrict__ tmp) {
+    __shared__ uint32_t hist[PT_SCHED_MAX_GROUPS][64];
+    for (int k = threadIdx.x; k < PT_SCHED_MAX_GROUPS * 64; k += PT_SCHED_THREADS) hist[k >> 6][k & 63] = 0;
     __syncthreads();
     const unsigned long long granule = sched_granule(tmp, max_split);
-    int begin, end;
-    sched_share(n, begin, end);
-    for (int i = begin + (int)threadIdx.x; i < end; i += blockDim.x) {
+    sched_for_tiles(cost, n, groups, tmp, [&](int, uint32_t c, int group) {
         int per_piece;
-        const uint32_t c = cost[i];
         const int k = sched_split(c, granule, num_samples, per_piece);
-        atomicAdd(&hist[sched_bucket(c / (uint32_t)k, sort)], (uint32_t)k);
-    }
+        atomicAdd(&hist[group][sched_bucket(c / (uint32_t)k, sort)], (uint32_t)k);
+    });
     __syncthreads();
-    if (threadIdx.x < 64) tmp[4 + 64 * blockIdx.x + threadIdx.x] = hist[threadIdx.x];
+    for (int k = threadIdx.x; k < groups * 64; k += PT_SCHED_THREADS) tmp[sched_counter(blockIdx.x, k >> 6, k & 63)] = hist[k >> 6][k & 63];
 }
 
-// One workgroup of 64 threads, thread = bucket: counts -> start of every workgroup's share of the bucket in the list
-// (most expensive bucket first); counts[0] <- number of items, counts[1] <- 0 (the scatter counts the split tiles there).
-__global__ __launch_bounds__(64) void pt_sched_offsets_kernel(uint32_t* __restrict__ tmp, uint32_t* __restrict__ counts) {
-    __shared__ uint32_t bucket_total[64], bucket_base[64];
+// One workgroup of 64 threads, thread = bucket: counts -> rank of every workgroup's first item of the bucket within its group
+// (most expensive bucket first); counts[0] <- list positions in use (groups x the longest group), counts[1] <- 0 (the scatter
+// counts the split tiles there).
+__global__ __launch_bounds__(64) void pt_sched_offsets_kernel(uint32_t* __restrict__ tmp, uint32_t* __restrict__ counts, int groups) {
+    __shared__ uint32_t bucket_total[PT_SCHED_MAX_GROUPS][64], bucket_base[PT_SCHED_MAX_GROUPS][64], group_items[PT_SCHED_MAX_GROUPS];
     const int b = threadIdx.x;
-    uint32_t running = 0;
-    for (int blk = 0; blk < PT_SCHED_BLOCKS; ++blk) {
-        const uint32_t v = tmp[4 + 64 * blk + b];
-        tmp[4 + 64 * blk + b] = running;
-        running += v;
+    for (int g = 0; g < groups; ++g) {
+        uint32_t running = 0;
+        for (int blk = 0; blk < PT_SCHED_BLOCKS; ++blk) {
+            const uint32_t v = tmp[sched_counter(blk, g, b)];
+            tmp[sched_counter(blk, g, b)] = running;
+            running += v;
+        }
+        bucket_total[g][b] = running;
     }
-    bucket_total[b] = running;
+    __syncthreads();
+    if (b < groups) {
+        uint32_t acc = 0;
+        for (int k = 63; k >= 0; --k) { bucket_base[b][k] = acc; acc += bucket_total[b][k]; }
+        group_items[b] = acc;
+        tmp[4 + b] = acc;
+    }
     __syncthreads();
     if (b == 0) {
-        uint32_t acc = 0;
-        for (int k = 63; k >= 0; --k) { bucket_base[k] = acc; acc += bucket_total[k]; }
-        counts[0] = acc;
+        uint32_t longest = 0;
+        for (int g = 0; g < groups; ++g) longest = max(longest, group_items[g]);
+        tmp[2] = longest;
+        counts[0] = longest * (uint32_t)groups;
         counts[1] = 0;
     }
-    __syncthreads();
-    const uint32_t base = bucket_base[b];
-    for (int blk = 0; blk < PT_SCHED_BLOCKS; ++blk) tmp[4 + 64 * blk + b] += base;
+    for (int g = 0; g < groups; ++g) {
+        const uint32_t base = bucket_base[g][b];
+        for (int blk = 0; blk < PT_SCHED_BLOCKS; ++blk) tmp[sched_counter(blk, g, b)] += base;
+    }
 }
 
 __global__ __launch_bounds__(PT_SCHED_THREADS) void pt_sched_scatter_kernel(const uint32_t* __restrict__ cost, int n, int num_samples, int max_split,
-                                                                            int sort, const uint32_t* __restrict__ tmp, PtWorkItem* __restrict__ items,
+                                                                            int sort, int groups, const uint32_t* __restrict__ tmp, PtWorkItem* __restrict__ items,
                                                                             uint32_t* __restrict__ counts, uint32_t* __restrict__ split_tiles) {
-    __shared__ uint32_t cursor[64];
-    if (threadIdx.x < 64) cursor[threadIdx.x] = tmp[4 + 64 * blockIdx.x + threadIdx.x];
+    __shared__ uint32_t cursor[PT_SCHED_MAX_GROUPS][64];
+    for (int k = threadIdx.x; k < groups * 64; k += PT_SCHED_THREADS) cursor[k >> 6][k & 63] = tmp[sched_counter(blockIdx.x, k >> 6, k & 63)];
     __syncthreads();
+    if (groups > 1) {
+        // positions past the end of a group that is shorter than the longest one: nothing to render there
+        const uint32_t positions = tmp[2] * (uint32_t)groups, per = (positions + PT_SCHED_BLOCKS - 1) / PT_SCHED_BLOCKS;
+        const uint32_t first = blockIdx.x * per, last = min(positions, first + per);
+        for (uint32_t q = first + threadIdx.x; q < last; q += PT_SCHED_THREADS)
+            if (q / (uint32_t)groups >= tmp[4 + q % (uint32_t)groups]) {
+                PtWorkItem none;
+                none.tile = PT_NO_TILE; none.sample_begin = 0; none.sample_count = 0; none.scratch_slot = -1;
+                items[q] = none;
+            }
+    }
     const unsigned long long granule = sched_granule(tmp, max_split);
-    int begin, end;
-    sched_share(n, begin, end);
-    for (int i = begin + (int)threadIdx.x; i < end; i += blockDim.x) {
+    sched_for_tiles(cost, n, groups, tmp, [&](int i, uint32_t c, int group) {
         int per_piece;
-        const uint32_t c = cost[i];
         const int k = sched_split(c, granule, num_samples, per_piece);
-        const uint32_t first = atomicAdd(&cursor[sched_bucket(c / (uint32_t)k, sort)], (uint32_t)k);
+        const uint32_t first = atomicAdd(&cursor[group][sched_bucket(c / (uint32_t)k, sort)], (uint32_t)k);
         int slot = -1;
         if (k > 1) {
             slot = (int)atomicAdd(&counts[1], 1u);
@@ -2162,9 +2264,9 @@ __global__ __launch_bounds__(PT_SCHED_THREADS) void pt_sched_scatter_kernel(cons
             it.sample_begin = (uint32_t)(j * per_piece);
             it.sample_count = (uint32_t)(num_samples - j * per_piece < per_piece ? num_samples - j * per_piece : per_piece);
             it.scratch_slot = slot;
-            items[first + (uint32_t)j] = it;
+            items[(first + (uint32_t)j) * (uint32_t)groups + (uint32_t)group] = it;
         }
-    }
+    });
 }
 
 int window_tiles(const PtKernelParams& p) { return PT_TILES_ACROSS(p.win_w) * PT_TILES_ACROSS(p.win_h); }
@@ -2220,15 +2322,16 @@ hipError_t pt_launch_arith_selftest(unsigned long long* bad, hipStream_t stream)
 }
 
 hipError_t pt_launch_schedule_items(const uint32_t* tile_cost, PtWorkItem* items, uint32_t* sched_counts, uint32_t* split_tiles, uint32_t* sched_tmp,
-                                    int num_tiles, int num_samples, int max_split_tiles, int sort, hipStream_t stream) {
+                                    int num_tiles, int num_samples, int max_split_tiles, int sort, int groups, hipStream_t stream) {
     if (num_tiles <= 0) return hipSuccess;
-    hipError_t e = hipMemsetAsync(sched_tmp, 0, 4 * sizeof(uint32_t), stream);
+    if (groups < 1 || groups > PT_SCHED_MAX_GROUPS) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(sched_tmp, 0, PT_SCHED_SHARES * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     const dim3 grid(PT_SCHED_BLOCKS), block(PT_SCHED_THREADS);
     hipLaunchKernelGGL(pt_sched_total_kernel, grid, block, 0, stream, tile_cost, num_tiles, sched_tmp);
-    hipLaunchKernelGGL(pt_sched_count_kernel, grid, block, 0, stream, tile_cost, num_tiles, num_samples, max_split_tiles, sort, sched_tmp);
-    hipLaunchKernelGGL(pt_sched_offsets_kernel, dim3(1), dim3(64), 0, stream, sched_tmp, sched_counts);
-    hipLaunchKernelGGL(pt_sched_scatter_kernel, grid, block, 0, stream, tile_cost, num_tiles, num_samples, max_split_tiles, sort, sched_tmp, items,
+    hipLaunchKernelGGL(pt_sched_count_kernel, grid, block, 0, stream, tile_cost, num_tiles, num_samples, max_split_tiles, sort, groups, sched_tmp);
+    hipLaunchKernelGGL(pt_sched_offsets_kernel, dim3(1), dim3(64), 0, stream, sched_tmp, sched_counts, groups);
+    hipLaunchKernelGGL(pt_sched_scatter_kernel, grid, block, 0, stream, tile_cost, num_tiles, num_samples, max_split_tiles, sort, groups, sched_tmp, items,
                        sched_counts, split_tiles);
     return hipGetLastError();
 }
@@ -2256,7 +2359,11 @@ hipError_t pt_launch_grid_occ_flag(const unsigned long long* counters, unsigned 
 
 hipError_t pt_launch_render(const PtKernelParams& p, int program_kind, hipStream_t stream) {
     if (p.win_w <= 0 || p.win_h <= 0 || p.num_samples <= 0) return hipSuccess;
+#ifdef PT_V_XCD_BANDS
+    const dim3 grid(p.items ? p.max_items + 8 : window_tiles(p)), block(PT_TILE_THREADS);
+#else
     const dim3 grid(p.items ? p.max_items : window_tiles(p)), block(PT_TILE_THREADS);
+#endif
     if (program_kind == 2) {
         if (PT_TILE_WAVES != 1 || p.items) return hipErrorInvalidValue;
         hipLaunchKernelGGL(pt_cpu_tracer_kernel, dim3(window_tiles(p)), dim3(64), 0, stream, p);

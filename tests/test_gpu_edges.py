@@ -409,3 +409,39 @@ def test_targets_far_beyond_the_benchmark_sizes(workload, size, spp):
     ref, orays = po.render(sc, u, 1, spp, threads=16)
     assert n_bit_mismatch(img, ref) == 0
     assert rays == orays > W * H * spp
+
+
+@pytest.mark.parametrize("workload,size,shading,spp", [("suzanne", (640, 360), "reference", 40), ("instanced", (960, 540), "materials", 12),
+                                                        ("cornell", (333, 201), "reference", 33)])
+def test_work_list_dealt_to_the_xcds_changes_nothing(workload, size, shading, spp):
+    """PT_XCD_GROUPS=1 cuts the tiles into eight image bands of equal cost and gives each XCD one of them (list positions g,
+    g + 8, ...; bands differ in length, the gaps hold no work). Any list that covers every (tile, sample) once renders the same
+    image: compared with the single cost-ordered list over several dispatches (probe, first list, rebuilt list, split tiles)."""
+    import os
+    from pathtracer_amd import Tracer
+    from pathtracer_amd.scenes import SceneData
+    scene = SceneData(workload, *size)
+    out = {}
+    for groups in ("0", "1"):
+        old = os.environ.get("PT_XCD_GROUPS")
+        os.environ["PT_XCD_GROUPS"] = groups
+        try:
+            t = Tracer(0)
+        finally:
+            if old is None:
+                del os.environ["PT_XCD_GROUPS"]
+            else:
+                os.environ["PT_XCD_GROUPS"] = old
+        with t:
+            scene.upload(t, shading=shading)
+            t.target_create(scene.width, scene.height)
+            for k in range(4):
+                t.dispatch(1 + k * spp, spp, 1)
+            t.set_window(17, 9, scene.width - 40, scene.height - 30)
+            t.dispatch(1 + 4 * spp, spp, 1)
+            t.dispatch(1 + 5 * spp, spp, 1)
+            t.finish()
+            st = t.stats()
+            out[groups] = (t.readback().copy(), st["rays"], st["samples"])
+    assert np.array_equal(out["0"][0].view(np.uint32), out["1"][0].view(np.uint32))
+    assert out["0"][1:] == out["1"][1:]
