@@ -207,10 +207,14 @@ PtStatus pt_build_accel(PtContext* ctx);
 /* Which builder the next pt_build_accel uses. Images do not depend on it (the walk only ever skips triangles the exact test
  * could not accept); the time of the walks and of the build does. */
 typedef enum PtBvhBuilder {
-    PT_BVH_BUILDER_SAH = 0,    /* default: top-down on the host, splits by the binned surface-area heuristic, up to 16 threads;
-                                  0.09 s for a million triangles; its walks fetch 10-20 % fewer records */
-    PT_BVH_BUILDER_MORTON = 1  /* on the device: Morton codes, radix sort, Karras hierarchy; 11 ms for a million triangles --
-                                  for meshes that are rebuilt often */
+    PT_BVH_BUILDER_SAH = 0,    /* top-down on the HOST, splits by the binned surface-area heuristic, up to 16 threads;
+                                  0.09 s for a million triangles */
+    PT_BVH_BUILDER_MORTON = 1, /* on the device: Morton codes, radix sort, Karras hierarchy; the quickest build, and walks that
+                                  fetch 10-20 % more records than over the other two */
+    PT_BVH_BUILDER_PLOC = 2    /* default, on the device: triangles in Morton order merged bottom-up, each cluster with the
+                                  neighbour (within 16 places along the curve) that gives the smallest box, then re-ordered depth
+                                  first; meshes on which that makes no headway (degenerate layouts) get the Morton-code
+                                  hierarchy */
 } PtBvhBuilder;
 PtStatus pt_set_bvh_builder(PtContext* ctx, PtBvhBuilder builder);
 PtStatus pt_set_accel_mode(PtContext* ctx, PtAccelMode mode);

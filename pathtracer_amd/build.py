@@ -98,15 +98,14 @@ def build_all(force=False):
 
 
 def build_sanitize():
-    """The host's scene code and the parity oracle in one executable under AddressSanitizer + UndefinedBehaviorSanitizer (host
-    compiler only: oracle/Makefile target `asan`, run by tests/test_sanitizers.py)."""
-    _run(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "asan"])
-    return os.path.join(ROOT, "oracle", "_build", "sanitize_check")
+    """The host's scene code under AddressSanitizer + UndefinedBehaviorSanitizer (host compiler only), in the test executable
+    that tests/native/Makefile describes and tests/test_sanitizers.py runs. Returns nothing the product loads."""
+    _run(["make", "-C", os.path.join(ROOT, "tests", "native"), "-s", "asan"])
 
 
 if __name__ == "__main__":
     if "--sanitize" in sys.argv:
-        print(build_sanitize())
+        build_sanitize()
         sys.exit(0)
     for p in build_all(force="--force" in sys.argv):
         print(p)

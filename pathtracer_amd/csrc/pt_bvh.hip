@@ -232,51 +232,6 @@ __global__ void bvh_emit_qframe(const float* __restrict__ node_box, float scene_
 }
 
 // ---- wide nodes --------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bvh_parents(const int* __restrict__ child, int n, int* __restrict__ parent) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n - 1) return;
-    if (i == 0) parent[0] = -1;
-    for (int c = 0; c < 2; ++c) {
-        const int ref = child[2 * i + c];
-        if (ref >= 0) parent[ref] = i;
-    }
-}
-
-// flag[i] = 1 when binary node i becomes a wide node: an even number of ancestors, and more triangles below it than a leaf holds
-__global__ __launch_bounds__(256) void bvh_wide_flags(const int* __restrict__ parent, const int* __restrict__ range, int n, int* __restrict__ flag) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n - 1) return;
-    int depth = 0;
-    for (int j = parent[i]; j >= 0; j = parent[j]) ++depth;
-    flag[i] = ((depth & 1) == 0 && range[2 * i + 1] - range[2 * i] + 1 > PT_BVH_WIDE_LEAF_MAX) ? 1 : 0;
-}
-
-__global__ __launch_bounds__(256) void bvh_wide_indices(const int* __restrict__ flag, int n, int* __restrict__ wide_index) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n - 1) return;
-    if (!flag[i]) wide_index[i] = -1;  // (flagged entries hold the exclusive sum = their index)
-}
-
-// Children of the wide node made of binary node i, by the fixed rule: the children of i, an internal child (more triangles than a
-// leaf holds) replaced by ITS two children -- every second level of the binary tree disappears.
-__global__ __launch_bounds__(256) void bvh_wide_children(const int* __restrict__ child, const int* __restrict__ range,
-                                                         const int* __restrict__ wide_index, int n, int* __restrict__ wide_child) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n - 1 || wide_index[i] < 0) return;
-    int* out = wide_child + 4 * (size_t)wide_index[i];
-    int slot = 0;
-    for (int c = 0; c < 2; ++c) {
-        const int ref = child[2 * i + c];
-        if (traversal_ref(ref, range, PT_BVH_WIDE_LEAF_MAX) & 0x80000000u) {
-            out[slot++] = ref;
-        } else {
-            out[slot++] = child[2 * ref];
-            out[slot++] = child[2 * ref + 1];
-        }
-    }
-    for (; slot < 4; ++slot) out[slot] = PT_BVH_NO_WIDE_CHILD;
-}
-
 // Wide node of binary node i from its list of children (binary refs). Boxes are the ones bvh_emit_nodes pads (same pads,
 // absolute coordinates), rounded outwards to the frame's steps and one step further. A walk decodes a bound as
 // fma(q, step / d, (base - o) / d): its rounding is some 1e-7 of the scene's size in position, a step is 1.5e-5 of it.
@@ -477,9 +432,8 @@ struct SahBuilder {
     }
 };
 
-// Boxes bottom-up, for whatever made order / child / range (node 0 is the root); and, unless the builder has made its own, the
-// wide nodes by the fixed rule.
-hipError_t finish_topology(const PtBvhBuild& b, hipStream_t stream, int32_t* out_passes, bool number_wide) {
+// Boxes bottom-up, for whatever made order / child / range (node 0 is the root).
+hipError_t finish_topology(const PtBvhBuild& b, hipStream_t stream, int32_t* out_passes) {
     const int n = b.num_triangles;
     hipError_t e = hipMemsetAsync(b.done, 0, (size_t)(n - 1) * sizeof(int), stream);
     if (e != hipSuccess) return e;
@@ -500,15 +454,6 @@ hipError_t finish_topology(const PtBvhBuild& b, hipStream_t stream, int32_t* out
         if (e != hipSuccess) return e;
     }
     if (out_passes) *out_passes = pass - 1;
-    if (!number_wide) return hipGetLastError();
-    // numbering of the wide nodes (every second level)
-    hipLaunchKernelGGL(bvh_parents, grid_for(n - 1), dim3(256), 0, stream, b.child, n, b.parent);
-    hipLaunchKernelGGL(bvh_wide_flags, grid_for(n - 1), dim3(256), 0, stream, b.parent, b.range, n, b.wide_flag);
-    size_t bytes = b.sort_tmp_bytes;
-    e = hipcub::DeviceScan::ExclusiveSum(b.sort_tmp, bytes, b.wide_flag, b.wide_index, n - 1, stream);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(bvh_wide_indices, grid_for(n - 1), dim3(256), 0, stream, b.wide_flag, n, b.wide_index);
-    hipLaunchKernelGGL(bvh_wide_children, grid_for(n - 1), dim3(256), 0, stream, b.child, b.range, b.wide_index, n, b.wide_child);
     return hipGetLastError();
 }
 
@@ -685,29 +630,345 @@ hipError_t pt_bvh_build_topology_sah(const PtBvhBuild& b, hipStream_t stream, in
     if (report)
         fprintf(stderr, "[pt bvh] host builder, %d triangles: top of the tree %.1f ms, subtrees %.1f ms, wide nodes %.1f ms, upload %.1f ms\n", n,
                 ms_top, ms_subtrees, ms_wide, ms_since(t_upload));
-    return finish_topology(b, stream, out_passes, false);
+    return finish_topology(b, stream, out_passes);
 }
 
 size_t pt_bvh_sort_temp_bytes(int32_t n) {
-    size_t bytes = 0, scan = 0;
+    size_t bytes = 0, scan = 0, scan64 = 0;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
                                              (const uint32_t*)nullptr, (uint32_t*)nullptr, n, 0, 63, nullptr);
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan, (const int*)nullptr, (int*)nullptr, n, nullptr);  // numbering of the wide nodes
-    return bytes > scan ? bytes : scan;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan64, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, n, nullptr);  // cluster merging
+    return std::max(bytes, std::max(scan, scan64));
 }
+
+namespace {
+
+hipError_t morton_sorted_order(const PtBvhBuild& b, hipStream_t stream) {
+    const int n = b.num_triangles;
+    hipLaunchKernelGGL(bvh_init_scene_box, dim3(1), dim3(64), 0, stream, b.scene_box);
+    hipLaunchKernelGGL(bvh_tri_boxes, grid_for(n), dim3(256), 0, stream, b.vertices, b.indices, n, b.tri_box, b.scene_box);
+    hipLaunchKernelGGL(bvh_morton_keys, grid_for(n), dim3(256), 0, stream, b.tri_box, b.scene_box, n, b.keys_tmp, b.order_tmp);
+    size_t bytes = b.sort_tmp_bytes;
+    return hipcub::DeviceRadixSort::SortPairs(b.sort_tmp, bytes, b.keys_tmp, b.keys, b.order_tmp, b.order, n, 0, 63, stream);
+}
+
+// ---- wide nodes by box size, on the device -----------------------------------------------------------------------------------
+// A wide node's children: the two children of its binary node, then, while fewer than four, the child with the largest box that
+// is not a leaf of the wide form replaced by its own two children (the rule the host builder applies). Level by level from the
+// root: the nodes of one level are expanded side by side, their internal children numbered by a prefix sum and queued as the
+// next level, so the numbering (breadth first) does not depend on the order threads run in.
+__device__ __forceinline__ bool wide_leaf(int ref, const int* __restrict__ range) {
+    return ref < 0 || range[2 * ref + 1] - range[2 * ref] + 1 <= PT_BVH_WIDE_LEAF_MAX;
+}
+__device__ __forceinline__ float box_half_area(const float* __restrict__ box) {
+    const float x = box[3] - box[0], y = box[4] - box[1], z = box[5] - box[2];
+    return (x * y + y * z) + z * x;
+}
+
+__global__ __launch_bounds__(256) void bvh_wide_expand(const int* __restrict__ queue, int count, int first_index, const int* __restrict__ child,
+                                                       const int* __restrict__ range, const float* __restrict__ node_box, int* __restrict__ wide_index,
+                                                       int* __restrict__ wide_child, int* __restrict__ internal_children) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= count) return;
+    const int i = queue[q], w = first_index + q;
+    int slots[4] = {child[2 * i], child[2 * i + 1], PT_BVH_NO_WIDE_CHILD, PT_BVH_NO_WIDE_CHILD};
+    int used = 2;
+    while (used < 4) {
+        int pick = -1;
+        float pick_area = -1.0f;
+        for (int k = 0; k < used; ++k)
+            if (!wide_leaf(slots[k], range)) {
+                const float a = box_half_area(node_box + 6 * (size_t)slots[k]);
+                if (a > pick_area || pick < 0) { pick_area = a; pick = k; }   // (a NaN area never wins over an earlier pick)
+            }
+        if (pick < 0) break;
+        const int ref = slots[pick];
+        slots[pick] = child[2 * ref];
+        slots[used++] = child[2 * ref + 1];
+    }
+    wide_index[i] = w;
+    int internal = 0;
+    for (int k = 0; k < 4; ++k) {
+        wide_child[4 * (size_t)w + k] = slots[k];
+        internal += (k < used && !wide_leaf(slots[k], range)) ? 1 : 0;
+    }
+    internal_children[q] = internal;
+}
+
+__global__ __launch_bounds__(256) void bvh_wide_queue_next(int count, int first_index, const int* __restrict__ range, const int* __restrict__ wide_child,
+                                                           const int* __restrict__ offsets, int* __restrict__ next_queue) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= count) return;
+    int at = offsets[q];
+    for (int k = 0; k < 4; ++k) {
+        const int ref = wide_child[4 * (size_t)(first_index + q) + k];
+        if (ref != PT_BVH_NO_WIDE_CHILD && !wide_leaf(ref, range)) next_queue[at++] = ref;
+    }
+}
+
+// queue_a / queue_b / counts / offsets: n - 1 ints each (the builder's scratch arrays)
+hipError_t collapse_wide_on_device(const PtBvhBuild& b, int* queue_a, int* queue_b, int* counts, int* offsets, hipStream_t stream) {
+    const int n = b.num_triangles;
+    hipError_t e = hipMemsetAsync(b.wide_index, 0xff, (size_t)(n - 1) * sizeof(int), stream);
+    if (e != hipSuccess) return e;
+    const int root = 0;
+    e = hipMemcpyAsync(queue_a, &root, sizeof(int), hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(stream);   // (`root` leaves scope)
+    if (e != hipSuccess) return e;
+    int count = 1, first_index = 0;
+    for (int level = 0; count > 0; ++level) {
+        if (level > 4096) return hipErrorUnknown;
+        hipLaunchKernelGGL(bvh_wide_expand, grid_for(count), dim3(256), 0, stream, queue_a, count, first_index, b.child, b.range, b.node_box, b.wide_index,
+                           b.wide_child, counts);
+        size_t bytes = b.sort_tmp_bytes;
+        e = hipcub::DeviceScan::ExclusiveSum(b.sort_tmp, bytes, counts, offsets, count, stream);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(bvh_wide_queue_next, grid_for(count), dim3(256), 0, stream, count, first_index, b.range, b.wide_child, offsets, queue_b);
+        int last[2] = {0, 0};
+        e = hipMemcpyAsync(&last[0], offsets + (count - 1), sizeof(int), hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&last[1], counts + (count - 1), sizeof(int), hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) return e;
+        first_index += count;
+        count = last[0] + last[1];
+        std::swap(queue_a, queue_b);
+    }
+    return hipGetLastError();
+}
+
+// ---- device builder: clusters merged with their nearest neighbours along the Morton curve ------------------------------------
+// (Parallel locally-ordered clustering, Meister and Bittner 2018.) The triangles start as one cluster each, in Morton order. In
+// every round a cluster looks `kPlocRadius` places to either side for the neighbour with which it would have the smallest box;
+// two clusters that choose each other merge into a node; the clusters are compacted, order kept. Merging what is close in SPACE,
+// whatever the Morton code says about it, gives hierarchies close to a surface-area-heuristic build's (measured in materials
+// mode: the walks fetch 1 % to 9 % more records than over the host builder's, against 10 % to 20 % more over the Morton-code
+// tree), at the price of subtrees whose leaves are no longer neighbours in Morton order: when the tree stands, the triangles
+// are re-ordered depth first, so that every subtree is a contiguous range again. A wider search (32 to 128 places) changes the
+// records fetched by under 1 % and costs build time, so the radius stays small.
+constexpr int kPlocRadius = 16;
+constexpr int kPlocSearchAllBelow = 256;
+
+struct PlocCluster {
+    float lo[3];
+    int ref;      // >= 0: node (creation order); < 0: ~(sorted position of a triangle)
+    float hi[3];
+    int count;    // triangles below
+};
+static_assert(sizeof(PlocCluster) == 32, "two 16-byte halves");
+
+__global__ __launch_bounds__(256) void ploc_init(const uint32_t* __restrict__ order, const float* __restrict__ tri_box, int n, PlocCluster* __restrict__ c) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* box = tri_box + 6 * (size_t)order[i];
+    PlocCluster k;
+    for (int a = 0; a < 3; ++a) { k.lo[a] = box[a]; k.hi[a] = box[3 + a]; }
+    k.ref = ~i;
+    k.count = 1;
+    c[i] = k;
+}
+
+__device__ __forceinline__ float merged_half_area(const PlocCluster& a, const PlocCluster& b) {
+    const float x = fmaxf(a.hi[0], b.hi[0]) - fminf(a.lo[0], b.lo[0]), y = fmaxf(a.hi[1], b.hi[1]) - fminf(a.lo[1], b.lo[1]),
+                z = fmaxf(a.hi[2], b.hi[2]) - fminf(a.lo[2], b.lo[2]);
+    return (x * y + y * z) + z * x;
+}
+
+__global__ __launch_bounds__(256) void ploc_nearest(const PlocCluster* __restrict__ c, int count, int radius, int* __restrict__ nn) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const PlocCluster me = c[i];
+    int best = i + 1 < count ? i + 1 : i - 1;   // (a cluster whose every candidate has a NaN box still names a neighbour)
+    float best_area = 3.0e38f;
+    const int lo = max(0, i - radius), hi = min(count - 1, i + radius);
+    for (int j = lo; j <= hi; ++j) {
+        if (j == i) continue;
+        const float a = merged_half_area(me, c[j]);
+        if (a < best_area) { best_area = a; best = j; }   // (equal boxes: the lower index)
+    }
+    nn[i] = best;
+}
+
+// low half: 1 = the cluster stays in the list (alone, or as the merged one); high half: 1 = it merges with nn[i] (the lower of the two)
+__global__ __launch_bounds__(256) void ploc_flags(const int* __restrict__ nn, int count, unsigned long long* __restrict__ flags) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const int j = nn[i];
+    const bool mutual = nn[j] == i;
+    flags[i] = (unsigned long long)((mutual && j < i) ? 0u : 1u) | ((unsigned long long)((mutual && i < j) ? 1u : 0u) << 32);
+}
+
+__global__ __launch_bounds__(256) void ploc_apply(const PlocCluster* __restrict__ in, const int* __restrict__ nn, const unsigned long long* __restrict__ flags,
+                                                  const unsigned long long* __restrict__ scan, int count, int first_node, PlocCluster* __restrict__ out,
+                                                  int* __restrict__ child, int* __restrict__ left_count, int* __restrict__ node_count,
+                                                  int* __restrict__ parent, int* __restrict__ leaf_parent, int* __restrict__ totals) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const unsigned long long f = flags[i], s = scan[i];
+    if (i == count - 1) {
+        totals[0] = (int)(uint32_t)(s + f);            // clusters that stay
+        totals[1] = (int)(uint32_t)((s + f) >> 32);    // nodes made
+    }
+    if (!(uint32_t)f) return;
+    PlocCluster k = in[i];
+    if ((uint32_t)(f >> 32)) {
+        const PlocCluster o = in[nn[i]];
+        const int node = first_node + (int)(uint32_t)(s >> 32);
+        child[2 * node] = k.ref;
+        child[2 * node + 1] = o.ref;
+        left_count[node] = k.count;
+        node_count[node] = k.count + o.count;
+        // parent and side of the two children: node << 1 | (1 = right child)
+        if (k.ref < 0) leaf_parent[~k.ref] = node << 1; else parent[k.ref] = node << 1;
+        if (o.ref < 0) leaf_parent[~o.ref] = node << 1 | 1; else parent[o.ref] = node << 1 | 1;
+        for (int a = 0; a < 3; ++a) { k.lo[a] = fminf(k.lo[a], o.lo[a]); k.hi[a] = fmaxf(k.hi[a], o.hi[a]); }
+        k.ref = node;
+        k.count += o.count;
+    }
+    out[(uint32_t)s] = k;
+}
+
+// where the subtree below `up` (parent << 1 | side of the thing we start from) begins in depth-first leaf order
+__device__ __forceinline__ int ploc_first_leaf(int up, const int* __restrict__ parent, const int* __restrict__ left_count, int root) {
+    int first = 0;
+    for (;;) {
+        const int node = up >> 1;
+        if (up & 1) first += left_count[node];
+        if (node == root) return first;
+        up = parent[node];
+    }
+}
+
+__global__ __launch_bounds__(256) void ploc_leaf_positions(int n, const int* __restrict__ leaf_parent, const int* __restrict__ parent,
+                                                           const int* __restrict__ left_count, const uint32_t* __restrict__ order,
+                                                           int* __restrict__ new_pos, uint32_t* __restrict__ new_order) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int at = ploc_first_leaf(leaf_parent[p], parent, left_count, n - 2);
+    new_pos[p] = at;
+    new_order[at] = order[p];
+}
+
+// nodes in their final numbering (the root, made last, becomes node 0; children get larger indices than their parent)
+__global__ __launch_bounds__(256) void ploc_write_nodes(int n, const int* __restrict__ child_c, const int* __restrict__ parent, const int* __restrict__ left_count,
+                                                        const int* __restrict__ node_count, const int* __restrict__ new_pos, int* __restrict__ child,
+                                                        int* __restrict__ range) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n - 1) return;
+    const int id = n - 2 - k;
+    for (int c = 0; c < 2; ++c) {
+        const int ref = child_c[2 * k + c];
+        child[2 * id + c] = ref < 0 ? ~new_pos[~ref] : n - 2 - ref;
+    }
+    const int first = k == n - 2 ? 0 : ploc_first_leaf(parent[k], parent, left_count, n - 2);
+    range[2 * id] = first;
+    range[2 * id + 1] = first + node_count[k] - 1;
+}
+
+struct DeviceScratch {   // freed when the builder returns, whatever happened
+    std::vector<void*> ptrs;
+    ~DeviceScratch() { for (void* p : ptrs) (void)hipFree(p); }
+    template <typename T>
+    hipError_t get(T** out, size_t count) {
+        void* p = nullptr;
+        const hipError_t e = hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T));
+        if (e == hipSuccess) ptrs.push_back(p);
+        *out = static_cast<T*>(p);
+        return e;
+    }
+};
+
+}  // namespace
 
 hipError_t pt_bvh_build_topology(const PtBvhBuild& b, hipStream_t stream, int32_t* out_passes) {
     const int n = b.num_triangles;
     if (out_passes) *out_passes = 0;
     if (n < 2) return hipSuccess;
-    hipLaunchKernelGGL(bvh_init_scene_box, dim3(1), dim3(64), 0, stream, b.scene_box);
-    hipLaunchKernelGGL(bvh_tri_boxes, grid_for(n), dim3(256), 0, stream, b.vertices, b.indices, n, b.tri_box, b.scene_box);
-    hipLaunchKernelGGL(bvh_morton_keys, grid_for(n), dim3(256), 0, stream, b.tri_box, b.scene_box, n, b.keys_tmp, b.order_tmp);
-    size_t bytes = b.sort_tmp_bytes;
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(b.sort_tmp, bytes, b.keys_tmp, b.keys, b.order_tmp, b.order, n, 0, 63, stream);
+    hipError_t e = morton_sorted_order(b, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(bvh_hierarchy, grid_for(n - 1), dim3(256), 0, stream, b.keys, n, b.child, b.range);
-    return finish_topology(b, stream, out_passes, true);
+    e = finish_topology(b, stream, out_passes);
+    if (e != hipSuccess) return e;
+    DeviceScratch scratch;
+    int* q[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int k = 0; k < 4; ++k)
+        if ((e = scratch.get(&q[k], (size_t)(n - 1))) != hipSuccess) return e;
+    e = collapse_wide_on_device(b, q[0], q[1], q[2], q[3], stream);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(stream);
+}
+
+hipError_t pt_bvh_build_topology_ploc(const PtBvhBuild& b, hipStream_t stream, int32_t* out_passes) {
+    const int n = b.num_triangles;
+    if (out_passes) *out_passes = 0;
+    if (n < 2) return hipSuccess;
+    hipError_t e = morton_sorted_order(b, stream);
+    if (e != hipSuccess) return e;
+    const bool report = getenv("PT_DEBUG_SCHED") != nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
+    DeviceScratch scratch;
+    PlocCluster *ca = nullptr, *cb = nullptr;
+    int *nn = nullptr, *child_c = nullptr, *left_count = nullptr, *node_count = nullptr, *parent = nullptr, *leaf_parent = nullptr, *new_pos = nullptr, *totals = nullptr;
+    unsigned long long *flags = nullptr, *scan = nullptr;
+    const size_t nn_ = (size_t)n, ni = (size_t)(n - 1);
+    if ((e = scratch.get(&ca, nn_)) != hipSuccess || (e = scratch.get(&cb, nn_)) != hipSuccess || (e = scratch.get(&nn, nn_)) != hipSuccess ||
+        (e = scratch.get(&flags, nn_)) != hipSuccess || (e = scratch.get(&scan, nn_)) != hipSuccess || (e = scratch.get(&child_c, 2 * ni)) != hipSuccess ||
+        (e = scratch.get(&left_count, ni)) != hipSuccess || (e = scratch.get(&node_count, ni)) != hipSuccess || (e = scratch.get(&parent, ni)) != hipSuccess ||
+        (e = scratch.get(&leaf_parent, nn_)) != hipSuccess || (e = scratch.get(&new_pos, nn_)) != hipSuccess || (e = scratch.get(&totals, 2)) != hipSuccess)
+        return e;
+    hipLaunchKernelGGL(ploc_init, grid_for(n), dim3(256), 0, stream, b.order, b.tri_box, n, ca);
+    int count = n, nodes = 0, rounds = 0;
+    bool gave_up = false;
+    while (count > 1) {
+        // few clusters left: every cluster looks at all the others (the sorted order no longer limits the choice, and the
+        // search costs count * count, which is small here)
+        hipLaunchKernelGGL(ploc_nearest, grid_for(count), dim3(256), 0, stream, ca, count, count <= kPlocSearchAllBelow ? count : kPlocRadius, nn);
+        hipLaunchKernelGGL(ploc_flags, grid_for(count), dim3(256), 0, stream, nn, count, flags);
+        size_t bytes = b.sort_tmp_bytes;
+        e = hipcub::DeviceScan::ExclusiveSum(b.sort_tmp, bytes, flags, scan, count, stream);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(ploc_apply, grid_for(count), dim3(256), 0, stream, ca, nn, flags, scan, count, nodes, cb, child_c, left_count, node_count, parent,
+                           leaf_parent, totals);
+        int h[2] = {0, 0};
+        e = hipMemcpyAsync(h, totals, sizeof h, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) return e;
+        // Every round merges at least the closest pair. Layouts on which little more than that happens (cluster sizes in
+        // geometric progression, boxes that are not numbers) would take as many rounds as there are triangles and end in a chain
+        // deeper than the walks' stacks: those meshes get the Morton-code hierarchy, whose height is bounded.
+        if (h[1] < 1 || (count > 4096 && h[1] < count / 512) || ++rounds > 256) { gave_up = true; break; }
+        nodes += h[1];
+        count = h[0];
+        std::swap(ca, cb);
+    }
+    if (!gave_up && nodes != n - 1) return hipErrorUnknown;
+    if (!gave_up) {
+        hipLaunchKernelGGL(ploc_leaf_positions, grid_for(n), dim3(256), 0, stream, n, leaf_parent, parent, left_count, b.order, new_pos, b.order_tmp);
+        hipLaunchKernelGGL(ploc_write_nodes, grid_for(n - 1), dim3(256), 0, stream, n, child_c, parent, left_count, node_count, new_pos, b.child, b.range);
+        e = hipMemcpyAsync(b.order, b.order_tmp, nn_ * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream);
+        if (e != hipSuccess) return e;
+        e = finish_topology(b, stream, out_passes);
+        if (e != hipSuccess) return e;
+        // (the per-wave walk keeps PT_BVH_STACK entries: a hierarchy that could fill them is not used)
+        if (out_passes && *out_passes > PT_BVH_STACK - 16) gave_up = true;
+    }
+    if (gave_up) {
+        if (report) fprintf(stderr, "[pt bvh] cluster merging given up after %d rounds (%d clusters left): Morton-code hierarchy instead\n", rounds, count);
+        e = morton_sorted_order(b, stream);   // (the depth-first order may already have replaced the Morton order)
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(bvh_hierarchy, grid_for(n - 1), dim3(256), 0, stream, b.keys, n, b.child, b.range);
+        e = finish_topology(b, stream, out_passes);
+        if (e != hipSuccess) return e;
+    }
+    // wide nodes (scratch: four arrays of n - 1 ints, taken from what the merging no longer needs)
+    e = collapse_wide_on_device(b, nn, new_pos, left_count, node_count, stream);
+    if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(stream);
+    if (report)
+        fprintf(stderr, "[pt bvh] device builder, %d triangles: %d merging rounds, %d sweeps, %.2f ms with the wide nodes\n", n, rounds,
+                out_passes ? *out_passes : 0, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
+    return e;
 }
 
 hipError_t pt_bvh_emit(const PtBvhBuild& b, const float ro[3], const float* tris, const float* tris_abs, hipStream_t stream) {

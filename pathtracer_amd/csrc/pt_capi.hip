@@ -125,7 +125,7 @@ struct PtContext {
     bool bvh_trivial = false;        // pt_build_accel ran on a mesh small enough to be one leaf (no hierarchy kept)
     int32_t bvh_refit_passes = 0;
     PtAccelMode accel_mode = PT_ACCEL_AUTO;
-    PtBvhBuilder bvh_builder = PT_BVH_BUILDER_SAH;   // PT_BVH_BUILDER=morton / sah sets a context's initial choice
+    PtBvhBuilder bvh_builder = PT_BVH_BUILDER_PLOC;  // PT_BVH_BUILDER=ploc / morton / sah sets a context's initial choice
     // direction grid (optional, rebuilt with the records when the camera position changes)
     PtGridBuild grid{};
     PtGridBuild grid_spare{};   // the arrays of the other resolution (coarse while the fine grid is in use and the other way round),
@@ -303,7 +303,7 @@ void free_target(PtContext* ctx) {
 void free_bvh(PtContext* ctx) {
     PtBvhBuild& b = ctx->bvh;
     void* ptrs[] = {b.tri_box, b.scene_box, b.keys_tmp, b.keys, b.order_tmp, b.order, b.sort_tmp, b.child, b.range, b.node_box, b.done, b.remaining,
-                    b.nodes, b.sorted_tris, b.sorted_ids, b.nodes_abs, b.sorted_tris_abs, b.nodes_w, b.tris_q, b.qframe, b.parent, b.wide_index, b.wide_flag, b.wide_child};
+                    b.nodes, b.sorted_tris, b.sorted_ids, b.nodes_abs, b.sorted_tris_abs, b.nodes_w, b.tris_q, b.qframe, b.wide_index, b.wide_child};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     b = PtBvhBuild{};
@@ -773,7 +773,7 @@ PtStatus pt_create(int32_t device, PtContext** out_ctx) {
     if (const char* g = getenv("PT_SCHED_SORT")) ctx->sched_sort = atoi(g);
     if (const char* g = getenv("PT_XCD_GROUPS")) ctx->xcd_groups = atoi(g) != 0;
     if (const char* g = getenv("PT_AUTO_GRID")) ctx->auto_grid = g[0] != '0';
-    if (const char* g = getenv("PT_BVH_BUILDER")) ctx->bvh_builder = g[0] == 'm' ? PT_BVH_BUILDER_MORTON : PT_BVH_BUILDER_SAH;
+    if (const char* g = getenv("PT_BVH_BUILDER")) ctx->bvh_builder = g[0] == 'm' ? PT_BVH_BUILDER_MORTON : (g[0] == 's' ? PT_BVH_BUILDER_SAH : PT_BVH_BUILDER_PLOC);
     if (const char* g = getenv("PT_CAMERA_RAY_GRID")) ctx->camera_ray_grid = g[0] != '0';
     if (const char* g = getenv("PT_PRIMARY_CACHE")) ctx->primary_cache_enabled = g[0] != '0';
     if (const char* g = getenv("PT_GRID_OCC")) ctx->grid_occ_override = atoi(g) != 0;
@@ -1026,15 +1026,14 @@ PtStatus pt_build_accel(PtContext* ctx) {
     alloc(&b.nodes_abs, ni * PT_BVH_NODE_FLOATS * sizeof(float));
     alloc(&b.sorted_tris_abs, (nn + PT_TRI_PAD) * PT_TRI_FLOATS * sizeof(float));
     alloc(&b.nodes_w, ni * PT_BVH_WNODE_WORDS * sizeof(uint32_t));
-    alloc(&b.parent, ni * sizeof(int));
     alloc(&b.wide_index, ni * sizeof(int));
-    alloc(&b.wide_flag, ni * sizeof(int));
     alloc(&b.wide_child, ni * 4 * sizeof(int));
     alloc(&b.tris_q, (nn + PT_TRI_PAD) * PT_BVH_QTRI_FLOATS * sizeof(float));
     alloc(&b.qframe, 8 * sizeof(float));
     if (e == hipSuccess)
-        e = ctx->bvh_builder == PT_BVH_BUILDER_SAH ? pt_bvh_build_topology_sah(b, ctx->stream, &ctx->bvh_refit_passes)
-                                                   : pt_bvh_build_topology(b, ctx->stream, &ctx->bvh_refit_passes);
+        e = ctx->bvh_builder == PT_BVH_BUILDER_SAH      ? pt_bvh_build_topology_sah(b, ctx->stream, &ctx->bvh_refit_passes)
+            : ctx->bvh_builder == PT_BVH_BUILDER_MORTON ? pt_bvh_build_topology(b, ctx->stream, &ctx->bvh_refit_passes)
+                                                        : pt_bvh_build_topology_ploc(b, ctx->stream, &ctx->bvh_refit_passes);
     if (e != hipSuccess) {
         free_bvh(ctx);
         return fail(PT_ERR_HIP, "BVH build failed: %s", hipGetErrorString(e));
@@ -1048,7 +1047,8 @@ PtStatus pt_build_accel(PtContext* ctx) {
 PtStatus pt_set_bvh_builder(PtContext* ctx, PtBvhBuilder builder) {
     PtStatus s = bind(ctx);
     if (s != PT_OK) return s;
-    PT_REQUIRE(builder == PT_BVH_BUILDER_SAH || builder == PT_BVH_BUILDER_MORTON, PT_ERR_INVALID_ARGUMENT, "unknown BVH builder %d", (int)builder);
+    PT_REQUIRE(builder == PT_BVH_BUILDER_SAH || builder == PT_BVH_BUILDER_MORTON || builder == PT_BVH_BUILDER_PLOC, PT_ERR_INVALID_ARGUMENT,
+               "unknown BVH builder %d", (int)builder);
     ctx->bvh_builder = builder;
     return PT_OK;
 }

@@ -78,9 +78,7 @@ struct PtBvhBuild {
     float* nodes;                 // (n-1) x PT_BVH_NODE_FLOATS traversal records
     float* nodes_abs;             // (n-1) x PT_BVH_NODE_FLOATS, absolute boxes
     float* sorted_tris_abs;       // (n + PT_TRI_PAD) x PT_TRI_FLOATS: a, e1, e2 in leaf order
-    int* parent;                  // (n-1): binary parent of each internal node (-1 for the root)
-    int* wide_index;              // (n-1): index of the wide node made of this binary node, or -1 (odd level, or inside a leaf)
-    int* wide_flag;               // (n-1): scratch of the numbering
+    int* wide_index;              // (n-1): index of the wide node made of this binary node, or -1 (absorbed by a wide node, or inside a leaf)
     int* wide_child;              // (n-1) x 4: binary refs of each wide node's children (PT_BVH_NO_WIDE_CHILD: slot unused)
     uint32_t* nodes_w;            // up to (n-1) x PT_BVH_WNODE_WORDS: wide nodes, absolute boxes in 16-bit steps of the frame
     float* tris_q;                // (n + PT_TRI_PAD) x PT_BVH_QTRI_FLOATS: a, e1, e2, id in leaf order
@@ -124,8 +122,9 @@ hipError_t pt_grid_fill(const PtGridBuild& g, const float* tris, int32_t n, hipS
 
 size_t pt_bvh_sort_temp_bytes(int32_t n);
 // Morton codes, sort, hierarchy, boxes. Synchronises the stream (a handful of times) to learn when the refit is done.
-hipError_t pt_bvh_build_topology(const PtBvhBuild& b, hipStream_t stream, int32_t* out_passes);
-hipError_t pt_bvh_build_topology_sah(const PtBvhBuild& b, hipStream_t stream, int32_t* out_passes);  // host-side builder, same arrays
+hipError_t pt_bvh_build_topology(const PtBvhBuild& b, hipStream_t stream, int32_t* out_passes);       // Morton codes, Karras hierarchy
+hipError_t pt_bvh_build_topology_ploc(const PtBvhBuild& b, hipStream_t stream, int32_t* out_passes);  // clusters merged along the Morton curve (default)
+hipError_t pt_bvh_build_topology_sah(const PtBvhBuild& b, hipStream_t stream, int32_t* out_passes);   // host-side builder, same arrays
 // Traversal records for ray origin `ro` + triangle records/ids in leaf order (from the per-triangle records `tris`).
 hipError_t pt_bvh_emit(const PtBvhBuild& b, const float ro[3], const float* tris, const float* tris_abs, hipStream_t stream);
 

@@ -42,18 +42,19 @@ def both_modes(t, verts, idx, cam, W, H, normal_mode, spp=3, window=None):
             t.dispatch(1, spp, 1)
             t.finish()
         res[name] = (ids, ts, t.readback(), t.stats()["rays"])
-    # the hierarchy of the other builder (the default is the host's surface-area builder)
-    t.set_bvh_builder(capi.BVH_BUILDER_MORTON)
-    t.build_accel()
-    t.set_bvh_builder(capi.BVH_BUILDER_SAH)
-    t.set_accel_mode(capi.ACCEL_BVH)
-    t.target_clear()
-    t.reset_stats()
-    ids, ts = t.readback_primary()
-    if spp:
-        t.dispatch(1, spp, 1)
-        t.finish()
-    res["bvh_morton"] = (ids, ts, t.readback(), t.stats()["rays"])
+    # the hierarchies of the other two builders (the default merges clusters along the Morton curve, on the device)
+    for name, builder in (("bvh_morton", capi.BVH_BUILDER_MORTON), ("bvh_sah", capi.BVH_BUILDER_SAH)):
+        t.set_bvh_builder(builder)
+        t.build_accel()
+        t.set_bvh_builder(capi.BVH_BUILDER_PLOC)
+        t.set_accel_mode(capi.ACCEL_BVH)
+        t.target_clear()
+        t.reset_stats()
+        ids, ts = t.readback_primary()
+        if spp:
+            t.dispatch(1, spp, 1)
+            t.finish()
+        res[name] = (ids, ts, t.readback(), t.stats()["rays"])
     t.set_accel_mode(capi.ACCEL_AUTO)
     t.program_destroy(prog)
     return res
@@ -61,7 +62,7 @@ def both_modes(t, verts, idx, cam, W, H, normal_mode, spp=3, window=None):
 
 def assert_same(res):
     b = res["brute"]
-    for other in ("bvh", "bvh_morton", "cull", "grid"):
+    for other in ("bvh", "bvh_morton", "bvh_sah", "cull", "grid"):
         a = res[other]
         assert np.array_equal(a[0], b[0]), f"{other}: {(a[0] != b[0]).sum()} primary ids differ"
         assert n_bit_mismatch(a[1], b[1]) == 0, other
@@ -688,7 +689,8 @@ def test_self_check_reports_a_broken_structure(workload, size):
 def test_hierarchy_over_degenerate_layouts_stays_shallow():
     """Meshes on which a cost-driven split peels off a sliver per level: thousands of zero-area triangles strung along a line
     (every candidate plane costs 0, so the first one wins: a sixteenth of the range per level), and centroids in geometric
-    progression. The host builder halves ranges beyond a fixed depth, so the height stays far below the walks' fixed stacks
+    progression. The host builder halves ranges beyond a fixed depth, the device builder gives its cluster merging up when a round
+    merges next to nothing and builds the Morton-code hierarchy instead: either way the height stays below the walks' fixed stacks
     (PtStats::bvh_sweeps bounds it), and a camera at the far end of the string -- for which the deep child is the near one, the
     worst case for the stack -- gets the same hits as the loop over all triangles, in both shading modes."""
     from pathtracer_amd import Tracer, capi
@@ -712,36 +714,41 @@ def test_hierarchy_over_degenerate_layouts_stays_shallow():
     W, H = 96, 64
     sph, _ = po.reference_spheres_and_materials()
     with Tracer(0) as t:
-        for eye, target in (((62.0, 0.02, 0.01), (0.0, 0.0, 0.0)), ((-1.0, 0.01, 0.02), (60.0, 0.0, 0.0))):
+        for builder, eye, target, shading in ((capi.BVH_BUILDER_SAH, (62.0, 0.02, 0.01), (0.0, 0.0, 0.0), 0), (capi.BVH_BUILDER_SAH, (62.0, 0.02, 0.01), (0.0, 0.0, 0.0), 1),
+                                              (capi.BVH_BUILDER_SAH, (-1.0, 0.01, 0.02), (60.0, 0.0, 0.0), 1), (capi.BVH_BUILDER_PLOC, (62.0, 0.02, 0.01), (0.0, 0.0, 0.0), 0),
+                                              (capi.BVH_BUILDER_PLOC, (-1.0, 0.01, 0.02), (60.0, 0.0, 0.0), 1)):
             cam = po.camera(50.0, W, H, eye, target, (0.0, 1.0, 0.0))
-            for shading in (0, 1):
-                prog = t.program_create(capi.PROGRAM_MESH)
-                t.use_program(prog)
-                t.upload_spheres(sph)
-                t.upload_materials(mats)
-                t.upload_mesh(verts, idx)
-                t.upload_material_ids(mids)
-                t.set_normal_mode(1)
-                t.set_shading_mode(shading)
-                t.target_create(W, H)
-                t.set_uniforms(cam, len(idx), 10)
-                t.build_accel()
-                sweeps = t.stats()["bvh_sweeps"]
-                assert 8 <= sweeps <= 64, sweeps        # 40 cost-driven levels, then halving: 13 more for 6,400 triangles
-                t.set_accel_mode(capi.ACCEL_BVH)
-                c, bi, bt = t.verify_accel(2)
-                assert c >= W * H and (bi, bt) == (0, 0), (eye, shading, c, bi, bt)
-                t.dispatch(1, 3, 1)
-                t.finish()
-                walked = t.readback().copy()
-                t.set_accel_mode(capi.ACCEL_BRUTE)
-                t.target_clear()
-                t.dispatch(1, 3, 1)
-                t.finish()
-                assert n_bit_mismatch(walked, t.readback()) == 0
-                assert (t.readback_primary()[0] >= 0).sum() > 1000
-                t.set_accel_mode(capi.ACCEL_AUTO)
-                t.program_destroy(prog)
+            prog = t.program_create(capi.PROGRAM_MESH)
+            t.use_program(prog)
+            t.upload_spheres(sph)
+            t.upload_materials(mats)
+            t.upload_mesh(verts, idx)
+            t.upload_material_ids(mids)
+            t.set_normal_mode(1)
+            t.set_shading_mode(shading)
+            t.target_create(W, H)
+            t.set_uniforms(cam, len(idx), 10)
+            t.set_bvh_builder(builder)
+            t.build_accel()
+            t.set_bvh_builder(capi.BVH_BUILDER_PLOC)
+            sweeps = t.stats()["bvh_sweeps"]
+            # host builder: 40 cost-driven levels, then halving (13 more for 6,400 triangles); the device's cluster merging makes no
+            # headway on the string of zero-area boxes and hands over to the Morton-code hierarchy (at most 95 levels, usually ~30)
+            assert 8 <= sweeps <= (64 if builder == capi.BVH_BUILDER_SAH else 96), (builder, sweeps)
+            t.set_accel_mode(capi.ACCEL_BVH)
+            c, bi, bt = t.verify_accel(2)
+            assert c >= W * H and (bi, bt) == (0, 0), (builder, eye, shading, c, bi, bt)
+            t.dispatch(1, 3, 1)
+            t.finish()
+            walked = t.readback().copy()
+            t.set_accel_mode(capi.ACCEL_BRUTE)
+            t.target_clear()
+            t.dispatch(1, 3, 1)
+            t.finish()
+            assert n_bit_mismatch(walked, t.readback()) == 0
+            assert (t.readback_primary()[0] >= 0).sum() > 1000
+            t.set_accel_mode(capi.ACCEL_AUTO)
+            t.program_destroy(prog)
 
 
 @pytest.mark.parametrize("shading", ["reference", "materials"])

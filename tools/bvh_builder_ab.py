@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Materials mode through the hierarchy made by the device's Morton-code builder and by the host's surface-area builder
-(PT_BVH_BUILDER=sah): build time, dispatch time, records fetched per query, the self-check, and whether the images agree."""
+"""Materials mode through the hierarchy made by the device's Morton-code builder, by the host's surface-area builder and by the
+device's cluster-merging builder (PT_BVH_BUILDER=morton / sah / ploc): build time, dispatch time, records fetched per query, the self-check, and whether the images agree."""
 import argparse
 import hashlib
 import json
@@ -19,7 +19,7 @@ def main():
     ap.add_argument("--shading", default="materials")
     ap.add_argument("--accel", default="auto")
     ap.add_argument("--lib", default=None, help="a variant library (pathtracer_amd.build.build_hip(tag=...))")
-    ap.add_argument("--builders", default="morton,sah")
+    ap.add_argument("--builders", default="morton,sah,ploc")
     args = ap.parse_args()
     from pathtracer_amd import Tracer, capi
     from pathtracer_amd.scenes import SceneData
