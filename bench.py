@@ -94,7 +94,7 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-PMC_SIDECAR = os.path.join(ROOT, "profiles", "r02_pmc.json")
+PMC_SIDECAR = os.path.join(ROOT, "profiles", "r03_pmc.json")
 
 
 def config_key(workload, width, height, spp, shading, accel):
@@ -107,7 +107,7 @@ def pmc_entry(key):
     try:
         doc = json.load(open(PMC_SIDECAR))
     except (OSError, ValueError):
-        return None, "no profiles/r02_pmc.json"
+        return None, "no profiles/r03_pmc.json"
     e = doc.get("entries", {}).get(key)
     if e is None:
         return None, "no PMC profile of this configuration"
@@ -215,7 +215,7 @@ def roofline(st, kernel_ms, scene, shading, pmc, pmc_note):
                 if pmc and pmc.get("loop_tests_past_backface_skip") is not None:
                     past_skip = pmc["loop_tests_past_backface_skip"]
                     out["loop_tests_past_backface_skip"] = past_skip
-                    out["loop_tests_past_backface_skip_source"] = "profiles/r02_pmc.json (counting build, same configuration)"
+                    out["loop_tests_past_backface_skip_source"] = "profiles/r03_pmc.json (counting build, same configuration)"
                 else:
                     out["loop_tests_past_backface_skip"] = "not counted in the product build: only the part of a test before the skip is priced"
             flop += per_lane_tests * (first + rest * past_skip) + per["shaded_hits"] * FLOP["test_accept"]

@@ -743,7 +743,7 @@ hipError_t collapse_wide_on_device(const PtBvhBuild& b, int* queue_a, int* queue
 // every round a cluster looks `kPlocRadius` places to either side for the neighbour with which it would have the smallest box;
 // two clusters that choose each other merge into a node; the clusters are compacted, order kept. Merging what is close in SPACE,
 // whatever the Morton code says about it, gives hierarchies close to a surface-area-heuristic build's (measured in materials
-// mode: the walks fetch 1 % to 9 % more records than over the host builder's, against 10 % to 20 % more over the Morton-code
+// mode: the walks fetch -1 % to +9 % more records than over the host builder's, against 8 % to 21 % more over the Morton-code
 // tree), at the price of subtrees whose leaves are no longer neighbours in Morton order: when the tree stands, the triangles
 // are re-ordered depth first, so that every subtree is a contiguous range again. A wider search (32 to 128 places) changes the
 // records fetched by under 1 % and costs build time, so the radius stays small.
@@ -781,10 +781,15 @@ __global__ __launch_bounds__(256) void ploc_nearest(const PlocCluster* __restric
     const PlocCluster me = c[i];
     int best = i + 1 < count ? i + 1 : i - 1;   // (a cluster whose every candidate has a NaN box still names a neighbour)
     float best_area = 3.0e38f;
+    const float mine = merged_half_area(me, me);
     const int lo = max(0, i - radius), hi = min(count - 1, i + radius);
     for (int j = lo; j <= hi; ++j) {
         if (j == i) continue;
-        const float a = merged_half_area(me, c[j]);
+        // what the merge adds: the merged box's area less three quarters of the two it replaces. (Measured on four meshes against
+        // the plain merged area, the full difference and the difference to the larger one: records fetched per query 3 % fewer
+        // than with the plain area on average; the full difference builds chains, 25 % to 90 % more.)
+        const PlocCluster other = c[j];
+        const float a = merged_half_area(me, other) - 0.75f * (mine + merged_half_area(other, other));
         if (a < best_area) { best_area = a; best = j; }   // (equal boxes: the lower index)
     }
     nn[i] = best;

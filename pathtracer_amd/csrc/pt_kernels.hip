@@ -851,15 +851,8 @@ __device__ __forceinline__ void park(float4* e, float sr, float sg, float sb, fl
 // Which entry of the work list a block takes. Blocks are handed to the eight XCDs (each with its own L2) round-robin by block index.
 __device__ __forceinline__ bool work_item_index(const PtKernelParams& p, unsigned& index) {
     const unsigned n = *(const kuint32*)p.sched_counts;
-#ifdef PT_V_XCD_BANDS
-    // experiment: XCD x takes the x-th contiguous eighth of the list
-    const unsigned per = (n + 7u) / 8u, j = blockIdx.x >> 3;
-    index = (blockIdx.x & 7u) * per + j;
-    return j < per && index < n;
-#else
     index = blockIdx.x;
     return index < n;
-#endif
 }
 
 // KIND: 0 sphere scene, 1 all-triangles loop, 2 LBVH, 3 culled loop. MATERIALS: false = the reference's shading (Phong
@@ -1200,6 +1193,11 @@ __device__ __forceinline__ int walk_round(const PtKernelParams& p, LaneWalk& w, 
         if (go) {
             const size_t at = 4 * (size_t)w.ref;
             const uint4 c0 = nodes[at], c1 = nodes[at + 1], c2 = nodes[at + 2], c3 = nodes[at + 3];
+#ifdef PT_V_EXTRA_VALU
+            // measurement build: vector instructions that do nothing, to see how the time follows the instruction count
+#pragma unroll
+            for (int k_ = 0; k_ < PT_V_EXTRA_VALU; ++k_) { int t_; asm volatile("v_mov_b32 %0, 0" : "=v"(t_)); }
+#endif
             const float limit = w.h.t * 1.0001f;
             const float inf = __builtin_inff();
             float n0, n1, n2, n3, f;
@@ -2359,11 +2357,7 @@ hipError_t pt_launch_grid_occ_flag(const unsigned long long* counters, unsigned 
 
 hipError_t pt_launch_render(const PtKernelParams& p, int program_kind, hipStream_t stream) {
     if (p.win_w <= 0 || p.win_h <= 0 || p.num_samples <= 0) return hipSuccess;
-#ifdef PT_V_XCD_BANDS
-    const dim3 grid(p.items ? p.max_items + 8 : window_tiles(p)), block(PT_TILE_THREADS);
-#else
     const dim3 grid(p.items ? p.max_items : window_tiles(p)), block(PT_TILE_THREADS);
-#endif
     if (program_kind == 2) {
         if (PT_TILE_WAVES != 1 || p.items) return hipErrorInvalidValue;
         hipLaunchKernelGGL(pt_cpu_tracer_kernel, dim3(window_tiles(p)), dim3(64), 0, stream, p);

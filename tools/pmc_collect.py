@@ -8,8 +8,8 @@ On the GPU box:    python3 tools/pmc_collect.py <tag> [bench.py arguments, e.g. 
       gpurun_out/pmc/<tag>_kernel_stats.csv   rocprofv3's kernel statistics of the same command
       gpurun_out/pmc/<tag>_bench.json         the bench line of the kernel-trace run
 Here, afterwards:  python3 tools/pmc_collect.py --merge
-  folds every gpurun_out/pmc/*.json into profiles/r02_pmc.json (keyed by configuration) and copies the statistics files
-  to profiles/r02_kernel_stats_<tag>.csv.
+  folds every gpurun_out/pmc/*.json into profiles/r03_pmc.json (keyed by configuration) and copies the statistics files
+  to profiles/r03_kernel_stats_<tag>.csv.
 
 Every entry carries the hash of the kernel sources it was taken from; bench.py ignores entries whose hash is not the
 current one. Units as rocprofv3 reports them: FETCH_SIZE / WRITE_SIZE in KiB; FETCH_SIZE is doubled (on gfx950 it reports
@@ -169,7 +169,7 @@ def collect(tag, bench_args):
 
 
 def merge():
-    path = os.path.join(ROOT, "profiles", "r02_pmc.json")
+    path = os.path.join(ROOT, "profiles", "r03_pmc.json")
     doc = json.load(open(path)) if os.path.exists(path) else {"entries": {}}
     doc["about"] = "written by tools/pmc_collect.py --merge from rocprofv3 runs on MI355X; bench.py reads the entry of its configuration"
     for f in sorted(glob.glob(os.path.join(OUT, "*.json"))):
@@ -181,10 +181,10 @@ def merge():
         doc["entries"][e["key"]] = e
         s = os.path.join(OUT, f"{tag}_kernel_stats.csv")
         if os.path.exists(s):
-            shutil.copy(s, os.path.join(ROOT, "profiles", f"r02_kernel_stats_{tag}.csv"))
+            shutil.copy(s, os.path.join(ROOT, "profiles", f"r03_kernel_stats_{tag}.csv"))
         b = os.path.join(OUT, f"{tag}_bench.json")
         if os.path.exists(b):
-            shutil.copy(b, os.path.join(ROOT, "profiles", f"r02_bench_under_rocprof_{tag}.json"))
+            shutil.copy(b, os.path.join(ROOT, "profiles", f"r03_bench_under_rocprof_{tag}.json"))
         print("merged", e["key"])
     json.dump(doc, open(path, "w"), indent=1)
 

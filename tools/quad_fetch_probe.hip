@@ -4,7 +4,7 @@
 //   lane   each lane issues four 16-byte loads for its own record (64 different lines per load instruction);
 //   quad   the four lanes of a quad fetch their four records together: load instruction i brings the record of quad lane i,
 //          lane l its quarter l (16 different lines per instruction, 4 lanes per line); the owner then collects its quarters from
-//          its quad neighbours (here: the word that holds the successor, by a cross-lane read).
+//          its quad neighbours (here: the word that holds the successor, by a cross-lane register read).
 // Build: hipcc --offload-arch=gfx950 -O3 -o quad_fetch_probe tools/quad_fetch_probe.hip ; run: ./quad_fetch_probe [steps]
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -28,7 +28,25 @@ __global__ __launch_bounds__(64) void chase_lane(const uint4* __restrict__ buf, 
 }
 
 // `active` lanes own a chain (the first `active` lanes, as above); all four lanes of a quad take part in the loads of the quad's
-// active owners
+// active owners. The cross-lane reads are DPP quad permutes (register moves: no LDS traffic that could hide the answer).
+template <int I>
+__device__ __forceinline__ uint32_t quad_read(uint32_t v) {  // the value quad lane I holds
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, I | (I << 2) | (I << 4) | (I << 6), 0xf, 0xf, true);
+}
+
+template <int I>
+__device__ __forceinline__ void quad_step(const uint4* __restrict__ buf, uint32_t idx, uint32_t l, uint32_t leader, int active, uint32_t mask,
+                                          uint32_t& next, uint32_t& acc) {
+    const uint32_t owner_idx = quad_read<I>(idx);
+    const bool owner_active = (int)(leader + I) < active;   // (uniform over the quad)
+    uint4 q = make_uint4(0, 0, 0, 0);
+    if (owner_active) q = buf[(size_t)owner_idx * 4 + l];
+    // the owner collects: successor = word 0 of quarter 0 (held by quad lane 0), and something of every quarter
+    const uint32_t w0 = quad_read<0>(q.x);
+    const uint32_t s1 = q.x + quad_read<1>(q.x) + quad_read<2>(q.x) + quad_read<3>(q.x);
+    if (l == (uint32_t)I) { next = w0 & mask; acc += s1; }
+}
+
 __global__ __launch_bounds__(64) void chase_quad(const uint4* __restrict__ buf, uint32_t mask, int steps, int active, uint32_t* out) {
     const uint32_t lane = threadIdx.x & 63, l = lane & 3u, leader = lane & ~3u;
     uint32_t idx = ((blockIdx.x * 64u + lane) * 2654435761u) & mask;
@@ -36,17 +54,10 @@ __global__ __launch_bounds__(64) void chase_quad(const uint4* __restrict__ buf, 
     const bool mine = (int)lane < active;
     for (int s = 0; s < steps; ++s) {
         uint32_t next = idx;
-#pragma unroll
-        for (uint32_t i = 0; i < 4; ++i) {
-            const uint32_t owner_idx = __shfl(idx, (int)(leader + i), 64);
-            const bool owner_active = (int)(leader + i) < active;   // (uniform over the quad)
-            uint4 q = make_uint4(0, 0, 0, 0);
-            if (owner_active) q = buf[(size_t)owner_idx * 4 + l];
-            // the owner collects: successor = word 0 of quarter 0 (held by quad lane 0), and something of every quarter
-            const uint32_t w0 = __shfl(q.x, (int)leader, 64);
-            const uint32_t s1 = q.x + __shfl(q.x, (int)(leader + 1), 64) + __shfl(q.x, (int)(leader + 2), 64) + __shfl(q.x, (int)(leader + 3), 64);
-            if (l == i) { next = w0 & mask; acc += s1; }
-        }
+        quad_step<0>(buf, idx, l, leader, active, mask, next, acc);
+        quad_step<1>(buf, idx, l, leader, active, mask, next, acc);
+        quad_step<2>(buf, idx, l, leader, active, mask, next, acc);
+        quad_step<3>(buf, idx, l, leader, active, mask, next, acc);
         if (mine) idx = next;
     }
     if (acc == 0x12345678u) out[blockIdx.x] = acc + idx;
