@@ -228,7 +228,9 @@ struct PtContext {
 namespace {
 
 constexpr size_t kCounterBytes = (size_t)PT_COUNTER_SLOTS * PT_COUNTER_STRIDE * sizeof(unsigned long long);
-constexpr int PT_MAX_SPLIT_FACTOR = 8;  // arrays of the scheduler are sized for this many split tiles per wave slot
+constexpr int PT_MAX_SPLIT_FACTOR = 32;  // arrays of the scheduler are sized for this many split tiles per wave slot
+constexpr float kEagerSplitFactor = 8.0f;     // views whose work sits in few tiles (loop, direction grid)
+constexpr float kWaveWalkSplitFactor = 32.0f; // the per-wave hierarchy walk of the reference shading
 constexpr size_t kXcdGroups = 8;        // XCDs of the device: blocks go to them round-robin by block index
 // PT_XCD_GROUPS=1 (off by default) deals the work list to the XCDs in image bands of equal cost, so that every XCD keeps reading
 // the records of one part of the scene. Measured on the 1M-triangle scene, materials mode, 16 samples at 4K: L2 hit rate 0.57 ->
@@ -1077,8 +1079,8 @@ static PtStatus target_common(PtContext* ctx, int32_t width, int32_t height) {
     PT_HIP_TRY(hipMalloc(&ctx->d_t, n * sizeof(float)));
     const size_t tiles = (size_t)PT_TILES_ACROSS(width) * PT_TILES_ACROSS(height);
     PT_HIP_TRY(hipMalloc(&ctx->d_tile_cost, tiles * sizeof(uint32_t)));
-    // (eight times the items: a list dealt to the XCDs leaves gaps where a band has fewer items than the longest one)
-    PT_HIP_TRY(hipMalloc(&ctx->d_items, kXcdGroups * (tiles + (size_t)PT_MAX_SPLIT_FACTOR * ctx->wave_slots) * sizeof(PtWorkItem)));
+    // (a list dealt to the XCDs leaves gaps where a band has fewer items than the longest one: eight times the items then)
+    PT_HIP_TRY(hipMalloc(&ctx->d_items, (ctx->xcd_groups != 0 ? kXcdGroups : 1) * (tiles + (size_t)PT_MAX_SPLIT_FACTOR * ctx->wave_slots) * sizeof(PtWorkItem)));
     PT_HIP_TRY(hipMalloc(&ctx->d_sched_counts, 2 * sizeof(uint32_t)));
     PT_HIP_TRY(hipMalloc(&ctx->d_sched_tmp, PT_SCHED_TMP_WORDS * sizeof(uint32_t)));
     PT_HIP_TRY(hipMalloc(&ctx->d_split_tiles, (size_t)PT_MAX_SPLIT_FACTOR * ctx->wave_slots * sizeof(uint32_t)));
@@ -1240,9 +1242,13 @@ PtStatus dispatch_range(PtContext* ctx, int32_t first_sample, int32_t num_sample
             // The per-lane walk of the materials mode sits between the two (1M triangles at 4K, 16 samples: 12.7 ms at factor 1, 14.0
             // at 4; 36 triangles through the hierarchy: 7.3 / 8.1; but 3,936 triangles at 1080p: 6.0 / 5.7, 968: 4.0 / 3.5, and
             // 6.1 / 3.9 at factor 16): factor 1, and 4 for a view found to be concentrated.
+            // The per-wave walk of the reference shading is one serial chain of dependent fetches per wave, and what bounds a
+            // dispatch is its longest chains: 1080p, 256 samples at factor 4 / 8 / 16 / 32 / 64: 3,936 triangles 21.6 / 17.4 / 12.5 /
+            // 10.8 / 9.9 ms, 968: 2.7 / 2.1 / 1.8 / 1.65 / 1.6, 1M triangles at 4K, 64 samples: 15.0 / 14.8 / 10.2 / 7.8 / 7.0, 36
+            // triangles: 23.3 at 32, 24.2 at 64. Factor 32 (parked samples: up to 2 GiB at these sizes).
             const float base_factor = ctx->split_factor >= 0.f ? std::min(ctx->split_factor, (float)PT_MAX_SPLIT_FACTOR)
-                                                               : (p.bvh_nodes ? 4.0f : kSpreadSplitFactor);
-            const float eager_factor = p.bvh_nodes_abs ? 4.0f : (float)PT_MAX_SPLIT_FACTOR;
+                                                               : (p.bvh_nodes ? kWaveWalkSplitFactor : kSpreadSplitFactor);
+            const float eager_factor = p.bvh_nodes_abs ? 4.0f : kEagerSplitFactor;
             const bool splitting = ctx->sched_mode == 2 && num_samples > 1;
             const int entry_bytes = is_materials(ctx->shading_mode) && prog->kind != PT_PROGRAM_WORLD ? 16 : 8;  // what a parked sample takes
             const size_t slot_bytes = (size_t)num_samples * PT_TILE_THREADS * (size_t)entry_bytes;
