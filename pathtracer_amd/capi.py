@@ -18,7 +18,7 @@ NORMALS_VERTEX, NORMALS_GEOMETRIC = 0, 1
 ACCUM_MEAN, ACCUM_SUM = 0, 1
 ACCEL_AUTO, ACCEL_BRUTE, ACCEL_BVH, ACCEL_CULL, ACCEL_GRID = 0, 1, 2, 3, 4
 SHADE_REFERENCE, SHADE_MATERIALS, SHADE_MATERIALS_UNIT = 0, 1, 2
-BVH_BUILDER_SAH, BVH_BUILDER_MORTON, BVH_BUILDER_PLOC = 0, 1, 2
+BVH_BUILDER_SAH, BVH_BUILDER_MORTON, BVH_BUILDER_PLOC, BVH_BUILDER_BINNED = 0, 1, 2, 3
 
 
 class PtUniforms(C.Structure):

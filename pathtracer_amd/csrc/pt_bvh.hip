@@ -976,6 +976,507 @@ hipError_t pt_bvh_build_topology_ploc(const PtBvhBuild& b, hipStream_t stream, i
     return e;
 }
 
+namespace {
+
+// ---- device builder: top-down, binned surface-area heuristic -------------------------------------------------------------------
+// SahBuilder::split's rules, level by level on the device. Ranges of more than kDevSmall triangles are split one level per round
+// of kernels over all positions: bounds of the centroids and the 3 x 16 bins of every range by atomics (a wave first gathers what
+// its 64 positions add to a range in registers), the plane per range, a flag per triangle, a prefix sum of the flags, a stable
+// partition into the other order array. Ranges of at most kDevSmall triangles are then finished by one wave each, which keeps the
+// triangles in LDS and splits until single triangles are left. Node indices are the host builder's (the subtree over c triangles
+// owns c - 1 consecutive indices, left subtree first), so parents can name their children before those exist.
+constexpr int kDevBins = SahBuilder::kBins;
+constexpr int kDevSmall = 64;
+constexpr int kDevPairs = 3 * kDevBins;   // (axis, bin) pairs of a range
+static_assert(kDevBins == 16 && kDevPairs <= 64, "a wave's lanes take one (axis, bin) pair each");
+
+__device__ __forceinline__ int dev_bin_of(float c, float lo, float scale) {   // SahBuilder::bin_of
+    const float f = (c - lo) * scale;
+    if (!(f > 0.f)) return 0;
+    return f >= (float)kDevBins ? kDevBins - 1 : (int)f;
+}
+__device__ __forceinline__ float dev_half_area(const float* lo, const float* hi) {   // HostBox::half_area
+    const float x = hi[0] - lo[0], y = hi[1] - lo[1], z = hi[2] - lo[2];
+    return x < 0.f ? 0.f : (x * y + y * z) + z * x;
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    for (int off = 32; off; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64); v = o < v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    for (int off = 32; off; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64); v = o > v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+    for (int off = 32; off; off >>= 1) { const unsigned long long o = __shfl_xor(v, off, 64); v = o < v ? o : v; }
+    return v;
+}
+// how many triangles of a range take part in choosing its plane: every stride-th (SahBuilder::split)
+__device__ __forceinline__ int dev_sample_stride(int count) { return count >= (1 << 17) ? count >> 14 : 1; }
+
+__global__ __launch_bounds__(256) void sahd_iota_ranges(int n, int* __restrict__ seg_of, int value) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) seg_of[p] = value;
+}
+
+__global__ __launch_bounds__(256) void sahd_reset(int ranges, uint32_t* __restrict__ cb, uint32_t* __restrict__ cnt, uint32_t* __restrict__ box) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (size_t)ranges * 6) cb[i] = (i % 6) < 3 ? 0xffffffffu : 0u;
+    if (i < (size_t)ranges * kDevPairs) cnt[i] = 0u;
+    if (i < (size_t)ranges * kDevPairs * 6) box[i] = (i % 6) < 3 ? 0xffffffffu : 0u;
+}
+
+// what position p adds to its range's statistics: the range, whether p is one of its samples, the triangle's box and centroid
+struct DevSample {
+    int range;
+    bool on;
+    float box[6], c[3];
+};
+__device__ __forceinline__ DevSample sahd_sample(int p, int n, const uint32_t* __restrict__ order, const float* __restrict__ tri_box,
+                                                 const int* __restrict__ seg_of, const int* __restrict__ seg_first, const int* __restrict__ seg_last) {
+    DevSample s;
+    s.range = p < n ? seg_of[p] : -1;
+    s.on = false;
+    for (int k = 0; k < 6; ++k) s.box[k] = 0.f;
+    for (int k = 0; k < 3; ++k) s.c[k] = 0.f;
+    if (s.range >= 0) {
+        const int first = seg_first[s.range], count = seg_last[s.range] - first + 1;
+        s.on = (p - first) % dev_sample_stride(count) == 0;
+        if (s.on) {
+            const float* b = tri_box + 6 * (size_t)order[p];
+            for (int k = 0; k < 6; ++k) s.box[k] = b[k];
+            for (int k = 0; k < 3; ++k) s.c[k] = 0.5f * b[k] + 0.5f * b[3 + k];
+        }
+    }
+    return s;
+}
+
+// bounds of the sampled centroids of every range (NaN coordinates take no part, as with std::min / std::max on the host)
+__global__ __launch_bounds__(256) void sahd_bounds(const uint32_t* __restrict__ order, const float* __restrict__ tri_box, const int* __restrict__ seg_of,
+                                                   const int* __restrict__ seg_first, const int* __restrict__ seg_last, int n, uint32_t* __restrict__ cb) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+    const DevSample s = sahd_sample(p, n, order, tri_box, seg_of, seg_first, seg_last);
+    // one range at a time (the 64 consecutive positions of a wave touch at most two ranges of more than 64 triangles)
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(s.on);
+    while (todo) {
+        const int leader = __builtin_ctzll(todo);
+        const int r0 = __shfl(s.range, leader, 64);
+        const bool mine = s.on && s.range == r0;
+        for (int k = 0; k < 3; ++k) {
+            const bool number = mine && s.c[k] == s.c[k];
+            const uint32_t lo = wave_min_u32(number ? f2ord(s.c[k]) : 0xffffffffu), hi = wave_max_u32(number ? f2ord(s.c[k]) : 0u);
+            if (lane == leader) {
+                atomicMin(&cb[6 * (size_t)r0 + k], lo);
+                atomicMax(&cb[6 * (size_t)r0 + 3 + k], hi);
+            }
+        }
+        todo &= ~__builtin_amdgcn_ballot_w64(mine);
+    }
+}
+
+// the 3 x 16 bins of every range: count and box of the sampled triangles whose centroid falls into the bin. Lane t < 48 of a
+// wave gathers pair t = (axis, bin) over the wave's 64 positions in registers and adds it to the range's bins when the range
+// changes and at the end.
+__global__ __launch_bounds__(256) void sahd_bins(const uint32_t* __restrict__ order, const float* __restrict__ tri_box, const int* __restrict__ seg_of,
+                                                 const int* __restrict__ seg_first, const int* __restrict__ seg_last, int n,
+                                                 const uint32_t* __restrict__ cb, uint32_t* __restrict__ cnt, uint32_t* __restrict__ box) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+    const DevSample s = sahd_sample(p, n, order, tri_box, seg_of, seg_first, seg_last);
+    int bin[3] = {0, 0, 0};
+    if (s.on)
+        for (int k = 0; k < 3; ++k) {
+            const float clo = ord2f(cb[6 * (size_t)s.range + k]), chi = ord2f(cb[6 * (size_t)s.range + 3 + k]);
+            const float scale = chi > clo ? (float)kDevBins / (chi - clo) : 0.f;
+            bin[k] = dev_bin_of(s.c[k], clo, scale);
+        }
+    const unsigned long long on = __builtin_amdgcn_ballot_w64(s.on);
+    if (!on) return;
+    const int my_axis = lane >> 4, my_bin = lane & 15;
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    uint32_t count = 0;
+    int current = -1;
+    auto flush = [&]() {
+        if (current >= 0 && lane < kDevPairs && count) {
+            const size_t at = (size_t)current * kDevPairs + lane;
+            atomicAdd(&cnt[at], count);
+            for (int k = 0; k < 3; ++k) {
+                atomicMin(&box[6 * at + k], f2ord(lo[k]));
+                atomicMax(&box[6 * at + 3 + k], f2ord(hi[k]));
+            }
+        }
+        for (int k = 0; k < 3; ++k) { lo[k] = 3.0e38f; hi[k] = -3.0e38f; }
+        count = 0;
+    };
+    for (int i = 0; i < 64; ++i) {
+        if (!((on >> i) & 1ull)) continue;   // (uniform)
+        const int r = __builtin_amdgcn_readlane(s.range, i);
+        if (r != current) { flush(); current = r; }
+        const int b0 = __builtin_amdgcn_readlane(bin[0], i), b1 = __builtin_amdgcn_readlane(bin[1], i), b2 = __builtin_amdgcn_readlane(bin[2], i);
+        float tb[6];
+        for (int k = 0; k < 6; ++k) tb[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s.box[k]), i));
+        const int its = my_axis == 0 ? b0 : (my_axis == 1 ? b1 : b2);
+        if (lane < kDevPairs && its == my_bin) {
+            for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], tb[k]); hi[k] = fmaxf(hi[k], tb[3 + k]); }   // (a NaN bound takes no part)
+            ++count;
+        }
+    }
+    flush();
+}
+
+// cost of the plane after bin `bin` of `axis` from the 16 bins of that axis (count, lo, hi each); +inf where one side is empty
+__device__ __forceinline__ float sahd_plane_cost(const int* __restrict__ count, const float (*lo)[3], const float (*hi)[3], int axis, int bin) {
+    float llo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, lhi[3] = {-3.0e38f, -3.0e38f, -3.0e38f}, rlo[3] = {3.0e38f, 3.0e38f, 3.0e38f},
+          rhi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    int left = 0, right = 0;
+    for (int j = 0; j < kDevBins; ++j) {
+        const int t = axis * kDevBins + j, c = count[t];
+        if (!c) continue;
+        if (j <= bin) {
+            left += c;
+            for (int k = 0; k < 3; ++k) { llo[k] = fminf(llo[k], lo[t][k]); lhi[k] = fmaxf(lhi[k], hi[t][k]); }
+        } else {
+            right += c;
+            for (int k = 0; k < 3; ++k) { rlo[k] = fminf(rlo[k], lo[t][k]); rhi[k] = fmaxf(rhi[k], hi[t][k]); }
+        }
+    }
+    if (left == 0 || right == 0) return __builtin_inff();
+    return dev_half_area(llo, lhi) * (float)left + dev_half_area(rlo, rhi) * (float)right;
+}
+// the cheapest of a wave's candidate planes (lane t: cost of pair t, +inf for none): the lowest t among equal costs, as the host's
+// loops with their strict '<'; -1 when no lane has a finite cost
+__device__ __forceinline__ int sahd_cheapest(float cost, int t) {
+    const uint32_t bits = __float_as_uint(cost);   // costs are sums of non-negative products: their bit patterns order like the values
+    const unsigned long long key = bits < 0x7f800000u ? ((unsigned long long)bits << 32) | (uint32_t)t : ~0ull;
+    const unsigned long long best = wave_min_u64(key);
+    return best == ~0ull ? -1 : (int)(uint32_t)best;
+}
+
+// one wave per range: the plane
+__global__ __launch_bounds__(64) void sahd_choose(const uint32_t* __restrict__ cb, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ box,
+                                                  int* __restrict__ axis, int* __restrict__ bin, float* __restrict__ plane_lo, float* __restrict__ plane_scale) {
+    __shared__ int count[kDevPairs];
+    __shared__ float lo[kDevPairs][3], hi[kDevPairs][3];
+    const int r = blockIdx.x, t = threadIdx.x;
+    if (t < kDevPairs) {
+        const size_t at = (size_t)r * kDevPairs + t;
+        count[t] = (int)cnt[at];
+        for (int k = 0; k < 3; ++k) { lo[t][k] = ord2f(box[6 * at + k]); hi[t][k] = ord2f(box[6 * at + 3 + k]); }
+    }
+    __syncthreads();
+    float cost = __builtin_inff(), clo = 0.f, scale = 0.f;
+    if (t < kDevPairs) {
+        const int k = t >> 4;
+        clo = ord2f(cb[6 * (size_t)r + k]);
+        const float chi = ord2f(cb[6 * (size_t)r + 3 + k]);
+        scale = chi > clo ? (float)kDevBins / (chi - clo) : 0.f;
+        if (scale != 0.f && (t & 15) < kDevBins - 1) cost = sahd_plane_cost(count, lo, hi, k, t & 15);
+    }
+    const int best = sahd_cheapest(cost, t);
+    if (best < 0) {
+        if (t == 0) axis[r] = -1;
+    } else if (t == best) {
+        axis[r] = t >> 4;
+        bin[r] = t & 15;
+        plane_lo[r] = clo;
+        plane_scale[r] = scale;
+    }
+}
+
+__global__ __launch_bounds__(256) void sahd_flags(const uint32_t* __restrict__ order, const float* __restrict__ tri_box, const int* __restrict__ seg_of, int n,
+                                                  const int* __restrict__ axis, const int* __restrict__ bin, const float* __restrict__ plane_lo,
+                                                  const float* __restrict__ plane_scale, int cost_driven, int* __restrict__ flags) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int r = seg_of[p];
+    int left = 0;
+    if (r >= 0 && cost_driven && axis[r] >= 0) {
+        const int k = axis[r];
+        const float* b = tri_box + 6 * (size_t)order[p];
+        left = dev_bin_of(0.5f * b[k] + 0.5f * b[3 + k], plane_lo[r], plane_scale[r]) <= bin[r] ? 1 : 0;
+    }
+    flags[p] = left;
+}
+
+// per range: where it is cut, its node, and its two parts as ranges of the next level (more than kDevSmall triangles), as work for
+// sahd_small (2 to kDevSmall) or as a leaf. counters[0] / [1]: ranges of the next level / small ranges so far.
+__global__ __launch_bounds__(256) void sahd_split(int ranges, const int* __restrict__ seg_first, const int* __restrict__ seg_last, const int* __restrict__ seg_node,
+                                                  const int* __restrict__ flags, const int* __restrict__ scan, int cost_driven, int depth, int* __restrict__ axis,
+                                                  int* __restrict__ cut, int* __restrict__ part_range, int* __restrict__ child, int* __restrict__ range,
+                                                  int* __restrict__ next_first, int* __restrict__ next_last, int* __restrict__ next_node, int* __restrict__ small_first,
+                                                  int* __restrict__ small_last, int* __restrict__ small_node, int* __restrict__ small_depth, int* __restrict__ counters) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= ranges) return;
+    const int first = seg_first[r], last = seg_last[r], node = seg_node[r], count = last - first + 1;
+    int a = cost_driven ? axis[r] : -1, at = 0;
+    if (a >= 0) {
+        const int left = scan[last] + flags[last] - scan[first];
+        at = first + left;
+        if (left <= 0 || at > last) a = -1;
+    }
+    if (a < 0) at = first + count / 2;   // halves, in the order the triangles stand in (Morton order within the range)
+    axis[r] = a;
+    cut[r] = at;
+    const int part_first[2] = {first, at}, part_last[2] = {at - 1, last}, part_node[2] = {node + 1, node + (at - first)};
+    range[2 * (size_t)node] = first;
+    range[2 * (size_t)node + 1] = last;
+    for (int side = 0; side < 2; ++side) {
+        const int c = part_last[side] - part_first[side] + 1;
+        child[2 * (size_t)node + side] = c == 1 ? ~part_first[side] : part_node[side];
+        int next = -1;
+        if (c > kDevSmall) {
+            next = atomicAdd(&counters[0], 1);
+            next_first[next] = part_first[side]; next_last[next] = part_last[side]; next_node[next] = part_node[side];
+        } else if (c >= 2) {
+            const int q = atomicAdd(&counters[1], 1);
+            small_first[q] = part_first[side]; small_last[q] = part_last[side]; small_node[q] = part_node[side]; small_depth[q] = depth + 1;
+        }
+        part_range[2 * (size_t)r + side] = next;
+    }
+}
+
+// the stable partition: every triangle to its place in the other order array, and the range of the next level it is in (-1: none)
+__global__ __launch_bounds__(256) void sahd_scatter(const uint32_t* __restrict__ order_in, const int* __restrict__ seg_of, int n, const int* __restrict__ seg_first,
+                                                    const int* __restrict__ axis, const int* __restrict__ cut, const int* __restrict__ part_range,
+                                                    const int* __restrict__ flags, const int* __restrict__ scan, uint32_t* __restrict__ order_out,
+                                                    int* __restrict__ seg_of_out) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int r = seg_of[p];
+    const uint32_t id = order_in[p];
+    if (r < 0) {
+        order_out[p] = id;
+        seg_of_out[p] = -1;
+        return;
+    }
+    const int first = seg_first[r], at = cut[r];
+    int to = p, side = p >= at ? 1 : 0;
+    if (axis[r] >= 0) {
+        const int left_before = scan[p] - scan[first];
+        side = flags[p] ? 0 : 1;
+        to = flags[p] ? first + left_before : at + (p - first - left_before);
+    }
+    order_out[to] = id;
+    seg_of_out[to] = part_range[2 * (size_t)r + side];
+}
+
+// One wave per range of 2 to kDevSmall triangles: the whole subtree, triangles kept in LDS. Same rules (SahBuilder::split with
+// stride 1); where no plane separates anything the range is halved after sorting it along its widest axis, which gives the halves
+// nth_element gives the host.
+__global__ __launch_bounds__(64) void sahd_small(int ranges, const int* __restrict__ small_first, const int* __restrict__ small_last,
+                                                 const int* __restrict__ small_node, const int* __restrict__ small_depth, uint32_t* __restrict__ order,
+                                                 const float* __restrict__ tri_box, int* __restrict__ child, int* __restrict__ range) {
+    __shared__ uint32_t ids[kDevSmall];
+    __shared__ float cen[kDevSmall][3], tb[kDevSmall][6];
+    __shared__ int st_lo[kDevSmall], st_hi[kDevSmall], st_node[kDevSmall], st_depth[kDevSmall];
+    __shared__ int count[kDevPairs];
+    __shared__ float blo[kDevPairs][3], bhi[kDevPairs][3];
+    const int q = blockIdx.x, t = threadIdx.x;
+    if (q >= ranges) return;
+    const int first = small_first[q], total = small_last[q] - first + 1;
+    if (t < total) {
+        const uint32_t id = order[first + t];
+        ids[t] = id;
+        const float* b = tri_box + 6 * (size_t)id;
+        for (int k = 0; k < 6; ++k) tb[t][k] = b[k];
+        for (int k = 0; k < 3; ++k) cen[t][k] = 0.5f * b[k] + 0.5f * b[3 + k];
+    }
+    if (t == 0) { st_lo[0] = 0; st_hi[0] = total - 1; st_node[0] = small_node[q]; st_depth[0] = small_depth[q]; }
+    int sp = 1;
+    __syncthreads();
+    while (sp > 0) {
+        --sp;
+        const int lo = __builtin_amdgcn_readfirstlane(st_lo[sp]), hi = __builtin_amdgcn_readfirstlane(st_hi[sp]),
+                  node = __builtin_amdgcn_readfirstlane(st_node[sp]), depth = __builtin_amdgcn_readfirstlane(st_depth[sp]);
+        const int c = hi - lo + 1;
+        const bool in = t >= lo && t <= hi;
+        float clo[3], chi[3], scale[3];
+        for (int k = 0; k < 3; ++k) {
+            const bool number = in && cen[in ? t : 0][k] == cen[in ? t : 0][k];
+            const float v = cen[in ? t : 0][k];
+            clo[k] = ord2f(wave_min_u32(number ? f2ord(v) : f2ord(3.0e38f)));
+            chi[k] = ord2f(wave_max_u32(number ? f2ord(v) : f2ord(-3.0e38f)));
+            scale[k] = chi[k] > clo[k] ? (float)kDevBins / (chi[k] - clo[k]) : 0.f;
+        }
+        int best = -1;
+        if (c > 2 && depth < SahBuilder::kMaxCostDepth) {
+            if (t < kDevPairs) {
+                const int k = t >> 4, j = t & 15;
+                float l3[3] = {3.0e38f, 3.0e38f, 3.0e38f}, h3[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+                int n_in = 0;
+                for (int i = lo; i <= hi; ++i)
+                    if (dev_bin_of(cen[i][k], clo[k], scale[k]) == j) {
+                        for (int a = 0; a < 3; ++a) { l3[a] = fminf(l3[a], tb[i][a]); h3[a] = fmaxf(h3[a], tb[i][3 + a]); }
+                        ++n_in;
+                    }
+                count[t] = n_in;
+                for (int a = 0; a < 3; ++a) { blo[t][a] = l3[a]; bhi[t][a] = h3[a]; }
+            }
+            __syncthreads();
+            float cost = __builtin_inff();
+            if (t < kDevPairs && scale[t >> 4] != 0.f && (t & 15) < kDevBins - 1) cost = sahd_plane_cost(count, blo, bhi, t >> 4, t & 15);
+            best = sahd_cheapest(cost, t);
+        }
+        // where every triangle of the range goes
+        int at = lo + c / 2, to = t;
+        bool moved = false;
+        if (best >= 0) {
+            const int k = best >> 4, j = best & 15;
+            const bool left = in && dev_bin_of(cen[in ? t : 0][k], clo[k], scale[k]) <= j;
+            const unsigned long long lefts = __builtin_amdgcn_ballot_w64(left), all = __builtin_amdgcn_ballot_w64(in);
+            const int n_left = __builtin_popcountll(lefts);
+            if (n_left > 0 && n_left < c) {
+                const unsigned long long below = (1ull << t) - 1ull;
+                at = lo + n_left;
+                to = left ? lo + __builtin_popcountll(lefts & below) : at + __builtin_popcountll(all & ~lefts & below);
+                moved = true;
+            }
+        }
+        if (!moved) {
+            int k = 0;
+            for (int a = 1; a < 3; ++a) if (chi[a] - clo[a] > chi[k] - clo[k]) k = a;
+            if (chi[k] > clo[k]) {
+                // rank by (centroid coordinate as ordered bits, triangle id): a total order whatever the values
+                const unsigned long long mine = ((unsigned long long)f2ord(cen[in ? t : 0][k]) << 32) | ids[in ? t : 0];
+                int rank = 0;
+                for (int i = lo; i <= hi; ++i) rank += ((((unsigned long long)f2ord(cen[i][k]) << 32) | ids[i]) < mine) ? 1 : 0;
+                to = lo + rank;
+                moved = true;
+            }
+        }
+        if (moved) {   // (uniform)
+            uint32_t id = 0;
+            float v[9];
+            if (in) {
+                id = ids[t];
+                for (int a = 0; a < 3; ++a) v[a] = cen[t][a];
+                for (int a = 0; a < 6; ++a) v[3 + a] = tb[t][a];
+            }
+            __syncthreads();
+            if (in) {
+                ids[to] = id;
+                for (int a = 0; a < 3; ++a) cen[to][a] = v[a];
+                for (int a = 0; a < 6; ++a) tb[to][a] = v[3 + a];
+            }
+        }
+        const int n_left = at - lo, n_right = hi - at + 1;
+        if (t == 0) {
+            range[2 * (size_t)node] = first + lo;
+            range[2 * (size_t)node + 1] = first + hi;
+            child[2 * (size_t)node] = n_left == 1 ? ~(first + lo) : node + 1;
+            child[2 * (size_t)node + 1] = n_right == 1 ? ~(first + at) : node + n_left;
+            int top = sp;
+            if (n_left > 1) { st_lo[top] = lo; st_hi[top] = at - 1; st_node[top] = node + 1; st_depth[top] = depth + 1; ++top; }
+            if (n_right > 1) { st_lo[top] = at; st_hi[top] = hi; st_node[top] = node + n_left; st_depth[top] = depth + 1; }
+        }
+        sp += (n_left > 1 ? 1 : 0) + (n_right > 1 ? 1 : 0);
+        __syncthreads();
+    }
+    if (t < total) order[first + t] = ids[t];
+}
+
+}  // namespace
+
+hipError_t pt_bvh_build_topology_binned(const PtBvhBuild& b, hipStream_t stream, int32_t* out_passes) {
+    const int n = b.num_triangles;
+    if (out_passes) *out_passes = 0;
+    if (n < 2) return hipSuccess;
+    // Morton order to start from: the partitions are stable, so a range stays in that order and its halves (where no plane
+    // separates anything) are halves in space as far as the curve allows
+    hipError_t e = morton_sorted_order(b, stream);
+    if (e != hipSuccess) return e;
+    const bool report = getenv("PT_DEBUG_SCHED") != nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
+    DeviceScratch scratch;
+    const size_t nn = (size_t)n, max_ranges = nn / (kDevSmall + 1) + 2, max_small = nn / 2 + 2;
+    int *seg[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}}, *seg_of[2] = {nullptr, nullptr}, *axis = nullptr, *bin = nullptr, *cut = nullptr,
+        *part_range = nullptr, *flags = nullptr, *scan = nullptr, *small[4] = {nullptr, nullptr, nullptr, nullptr}, *counters = nullptr;
+    float *plane_lo = nullptr, *plane_scale = nullptr;
+    uint32_t *cb = nullptr, *cnt = nullptr, *box = nullptr;
+    for (int a = 0; a < 2; ++a) {
+        for (int k = 0; k < 3; ++k)
+            if ((e = scratch.get(&seg[a][k], max_ranges)) != hipSuccess) return e;
+        if ((e = scratch.get(&seg_of[a], nn)) != hipSuccess) return e;
+    }
+    for (int k = 0; k < 4; ++k)
+        if ((e = scratch.get(&small[k], max_small)) != hipSuccess) return e;
+    if ((e = scratch.get(&axis, max_ranges)) != hipSuccess || (e = scratch.get(&bin, max_ranges)) != hipSuccess || (e = scratch.get(&cut, max_ranges)) != hipSuccess ||
+        (e = scratch.get(&part_range, 2 * max_ranges)) != hipSuccess || (e = scratch.get(&plane_lo, max_ranges)) != hipSuccess ||
+        (e = scratch.get(&plane_scale, max_ranges)) != hipSuccess || (e = scratch.get(&flags, nn)) != hipSuccess || (e = scratch.get(&scan, nn)) != hipSuccess ||
+        (e = scratch.get(&cb, 6 * max_ranges)) != hipSuccess || (e = scratch.get(&cnt, kDevPairs * max_ranges)) != hipSuccess ||
+        (e = scratch.get(&box, 6 * kDevPairs * max_ranges)) != hipSuccess || (e = scratch.get(&counters, 2)) != hipSuccess)
+        return e;
+    uint32_t* order[2] = {b.order, b.order_tmp};
+    int ranges = 0, smalls = 0, levels = 0, cur = 0;
+    e = hipMemsetAsync(counters, 0, 2 * sizeof(int), stream);
+    if (e != hipSuccess) return e;
+    {
+        const int root[4] = {0, n - 1, 0, 0};
+        if (n > kDevSmall) {
+            for (int k = 0; k < 3 && e == hipSuccess; ++k) e = hipMemcpyAsync(seg[0][k], &root[k], sizeof(int), hipMemcpyHostToDevice, stream);
+            hipLaunchKernelGGL(sahd_iota_ranges, grid_for(n), dim3(256), 0, stream, n, seg_of[0], 0);
+            ranges = 1;
+        } else {
+            for (int k = 0; k < 4 && e == hipSuccess; ++k) e = hipMemcpyAsync(small[k], &root[k], sizeof(int), hipMemcpyHostToDevice, stream);
+            smalls = 1;
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);   // (`root` leaves scope)
+        if (e != hipSuccess) return e;
+    }
+    while (ranges > 0) {
+        if (levels > 4096) return hipErrorUnknown;   // (a level halves its ranges at the latest from depth kMaxCostDepth on)
+        const int cost_driven = levels < SahBuilder::kMaxCostDepth ? 1 : 0;
+        int** s = seg[cur];
+        if (cost_driven) {
+            hipLaunchKernelGGL(sahd_reset, grid_for(ranges * kDevPairs * 6), dim3(256), 0, stream, ranges, cb, cnt, box);
+            hipLaunchKernelGGL(sahd_bounds, grid_for(n), dim3(256), 0, stream, order[cur], b.tri_box, seg_of[cur], s[0], s[1], n, cb);
+            hipLaunchKernelGGL(sahd_bins, grid_for(n), dim3(256), 0, stream, order[cur], b.tri_box, seg_of[cur], s[0], s[1], n, cb, cnt, box);
+            hipLaunchKernelGGL(sahd_choose, dim3((unsigned)ranges), dim3(64), 0, stream, cb, cnt, box, axis, bin, plane_lo, plane_scale);
+        }
+        hipLaunchKernelGGL(sahd_flags, grid_for(n), dim3(256), 0, stream, order[cur], b.tri_box, seg_of[cur], n, axis, bin, plane_lo, plane_scale, cost_driven, flags);
+        size_t bytes = b.sort_tmp_bytes;
+        e = hipcub::DeviceScan::ExclusiveSum(b.sort_tmp, bytes, flags, scan, n, stream);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(sahd_split, grid_for(ranges), dim3(256), 0, stream, ranges, s[0], s[1], s[2], flags, scan, cost_driven, levels, axis, cut, part_range,
+                           b.child, b.range, seg[cur ^ 1][0], seg[cur ^ 1][1], seg[cur ^ 1][2], small[0], small[1], small[2], small[3], counters);
+        hipLaunchKernelGGL(sahd_scatter, grid_for(n), dim3(256), 0, stream, order[cur], seg_of[cur], n, s[0], axis, cut, part_range, flags, scan, order[cur ^ 1],
+                           seg_of[cur ^ 1]);
+        int h[2] = {0, 0};
+        e = hipMemcpyAsync(h, counters, sizeof h, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipMemsetAsync(counters, 0, sizeof(int), stream);   // (the count of small ranges runs on)
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) return e;
+        if ((size_t)h[0] > max_ranges || (size_t)h[1] > max_small) return hipErrorUnknown;
+        ranges = h[0];
+        smalls = h[1];
+        cur ^= 1;
+        ++levels;
+    }
+    if (smalls > 0)
+        hipLaunchKernelGGL(sahd_small, dim3((unsigned)smalls), dim3(64), 0, stream, smalls, small[0], small[1], small[2], small[3], order[cur], b.tri_box, b.child,
+                           b.range);
+    if (cur != 0) {
+        e = hipMemcpyAsync(b.order, b.order_tmp, nn * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream);
+        if (e != hipSuccess) return e;
+    }
+    e = finish_topology(b, stream, out_passes);
+    if (e != hipSuccess) return e;
+    if (out_passes && *out_passes > PT_BVH_STACK - 16) {   // (cannot happen: cost-driven splits end at kMaxCostDepth; kept as a guard)
+        e = morton_sorted_order(b, stream);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(bvh_hierarchy, grid_for(n - 1), dim3(256), 0, stream, b.keys, n, b.child, b.range);
+        e = finish_topology(b, stream, out_passes);
+        if (e != hipSuccess) return e;
+    }
+    // wide nodes (scratch: four arrays of at least n - 1 ints that the build no longer needs)
+    e = collapse_wide_on_device(b, seg_of[0], seg_of[1], flags, scan, stream);
+    if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(stream);
+    if (report)
+        fprintf(stderr, "[pt bvh] device surface-area builder, %d triangles: %d levels of large ranges, %d small ranges, %d sweeps, %.2f ms with the wide nodes\n", n,
+                levels, smalls, out_passes ? *out_passes : 0, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
+    return e;
+}
+
 hipError_t pt_bvh_emit(const PtBvhBuild& b, const float ro[3], const float* tris, const float* tris_abs, hipStream_t stream) {
     const int n = b.num_triangles;
     if (n < 1) return hipSuccess;

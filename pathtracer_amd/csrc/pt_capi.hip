@@ -125,7 +125,7 @@ struct PtContext {
     bool bvh_trivial = false;        // pt_build_accel ran on a mesh small enough to be one leaf (no hierarchy kept)
     int32_t bvh_refit_passes = 0;
     PtAccelMode accel_mode = PT_ACCEL_AUTO;
-    PtBvhBuilder bvh_builder = PT_BVH_BUILDER_PLOC;  // PT_BVH_BUILDER=ploc / morton / sah sets a context's initial choice
+    PtBvhBuilder bvh_builder = PT_BVH_BUILDER_BINNED;  // PT_BVH_BUILDER=binned / ploc / morton / sah sets a context's initial choice
     // direction grid (optional, rebuilt with the records when the camera position changes)
     PtGridBuild grid{};
     PtGridBuild grid_spare{};   // the arrays of the other resolution (coarse while the fine grid is in use and the other way round),
@@ -775,7 +775,7 @@ PtStatus pt_create(int32_t device, PtContext** out_ctx) {
     if (const char* g = getenv("PT_SCHED_SORT")) ctx->sched_sort = atoi(g);
     if (const char* g = getenv("PT_XCD_GROUPS")) ctx->xcd_groups = atoi(g) != 0;
     if (const char* g = getenv("PT_AUTO_GRID")) ctx->auto_grid = g[0] != '0';
-    if (const char* g = getenv("PT_BVH_BUILDER")) ctx->bvh_builder = g[0] == 'm' ? PT_BVH_BUILDER_MORTON : (g[0] == 's' ? PT_BVH_BUILDER_SAH : PT_BVH_BUILDER_PLOC);
+    if (const char* g = getenv("PT_BVH_BUILDER")) ctx->bvh_builder = g[0] == 'm' ? PT_BVH_BUILDER_MORTON : (g[0] == 's' ? PT_BVH_BUILDER_SAH : (g[0] == 'p' ? PT_BVH_BUILDER_PLOC : PT_BVH_BUILDER_BINNED));
     if (const char* g = getenv("PT_CAMERA_RAY_GRID")) ctx->camera_ray_grid = g[0] != '0';
     if (const char* g = getenv("PT_PRIMARY_CACHE")) ctx->primary_cache_enabled = g[0] != '0';
     if (const char* g = getenv("PT_GRID_OCC")) ctx->grid_occ_override = atoi(g) != 0;
@@ -1035,6 +1035,7 @@ PtStatus pt_build_accel(PtContext* ctx) {
     if (e == hipSuccess)
         e = ctx->bvh_builder == PT_BVH_BUILDER_SAH      ? pt_bvh_build_topology_sah(b, ctx->stream, &ctx->bvh_refit_passes)
             : ctx->bvh_builder == PT_BVH_BUILDER_MORTON ? pt_bvh_build_topology(b, ctx->stream, &ctx->bvh_refit_passes)
+            : ctx->bvh_builder == PT_BVH_BUILDER_BINNED ? pt_bvh_build_topology_binned(b, ctx->stream, &ctx->bvh_refit_passes)
                                                         : pt_bvh_build_topology_ploc(b, ctx->stream, &ctx->bvh_refit_passes);
     if (e != hipSuccess) {
         free_bvh(ctx);
@@ -1049,7 +1050,8 @@ PtStatus pt_build_accel(PtContext* ctx) {
 PtStatus pt_set_bvh_builder(PtContext* ctx, PtBvhBuilder builder) {
     PtStatus s = bind(ctx);
     if (s != PT_OK) return s;
-    PT_REQUIRE(builder == PT_BVH_BUILDER_SAH || builder == PT_BVH_BUILDER_MORTON || builder == PT_BVH_BUILDER_PLOC, PT_ERR_INVALID_ARGUMENT,
+    PT_REQUIRE(builder == PT_BVH_BUILDER_SAH || builder == PT_BVH_BUILDER_MORTON || builder == PT_BVH_BUILDER_PLOC || builder == PT_BVH_BUILDER_BINNED,
+               PT_ERR_INVALID_ARGUMENT,
                "unknown BVH builder %d", (int)builder);
     ctx->bvh_builder = builder;
     return PT_OK;

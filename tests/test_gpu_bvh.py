@@ -42,11 +42,11 @@ def both_modes(t, verts, idx, cam, W, H, normal_mode, spp=3, window=None):
             t.dispatch(1, spp, 1)
             t.finish()
         res[name] = (ids, ts, t.readback(), t.stats()["rays"])
-    # the hierarchies of the other two builders (the default merges clusters along the Morton curve, on the device)
-    for name, builder in (("bvh_morton", capi.BVH_BUILDER_MORTON), ("bvh_sah", capi.BVH_BUILDER_SAH)):
+    # the hierarchies of the other three builders (the default is the device's binned surface-area builder)
+    for name, builder in (("bvh_morton", capi.BVH_BUILDER_MORTON), ("bvh_sah", capi.BVH_BUILDER_SAH), ("bvh_ploc", capi.BVH_BUILDER_PLOC)):
         t.set_bvh_builder(builder)
         t.build_accel()
-        t.set_bvh_builder(capi.BVH_BUILDER_PLOC)
+        t.set_bvh_builder(capi.BVH_BUILDER_BINNED)
         t.set_accel_mode(capi.ACCEL_BVH)
         t.target_clear()
         t.reset_stats()
@@ -62,7 +62,7 @@ def both_modes(t, verts, idx, cam, W, H, normal_mode, spp=3, window=None):
 
 def assert_same(res):
     b = res["brute"]
-    for other in ("bvh", "bvh_morton", "bvh_sah", "cull", "grid"):
+    for other in ("bvh", "bvh_morton", "bvh_sah", "bvh_ploc", "cull", "grid"):
         a = res[other]
         assert np.array_equal(a[0], b[0]), f"{other}: {(a[0] != b[0]).sum()} primary ids differ"
         assert n_bit_mismatch(a[1], b[1]) == 0, other
@@ -716,7 +716,8 @@ def test_hierarchy_over_degenerate_layouts_stays_shallow():
     with Tracer(0) as t:
         for builder, eye, target, shading in ((capi.BVH_BUILDER_SAH, (62.0, 0.02, 0.01), (0.0, 0.0, 0.0), 0), (capi.BVH_BUILDER_SAH, (62.0, 0.02, 0.01), (0.0, 0.0, 0.0), 1),
                                               (capi.BVH_BUILDER_SAH, (-1.0, 0.01, 0.02), (60.0, 0.0, 0.0), 1), (capi.BVH_BUILDER_PLOC, (62.0, 0.02, 0.01), (0.0, 0.0, 0.0), 0),
-                                              (capi.BVH_BUILDER_PLOC, (-1.0, 0.01, 0.02), (60.0, 0.0, 0.0), 1)):
+                                              (capi.BVH_BUILDER_PLOC, (-1.0, 0.01, 0.02), (60.0, 0.0, 0.0), 1), (capi.BVH_BUILDER_BINNED, (62.0, 0.02, 0.01), (0.0, 0.0, 0.0), 0),
+                                              (capi.BVH_BUILDER_BINNED, (62.0, 0.02, 0.01), (0.0, 0.0, 0.0), 1), (capi.BVH_BUILDER_BINNED, (-1.0, 0.01, 0.02), (60.0, 0.0, 0.0), 1)):
             cam = po.camera(50.0, W, H, eye, target, (0.0, 1.0, 0.0))
             prog = t.program_create(capi.PROGRAM_MESH)
             t.use_program(prog)
@@ -730,11 +731,12 @@ def test_hierarchy_over_degenerate_layouts_stays_shallow():
             t.set_uniforms(cam, len(idx), 10)
             t.set_bvh_builder(builder)
             t.build_accel()
-            t.set_bvh_builder(capi.BVH_BUILDER_PLOC)
+            t.set_bvh_builder(capi.BVH_BUILDER_BINNED)
             sweeps = t.stats()["bvh_sweeps"]
-            # host builder: 40 cost-driven levels, then halving (13 more for 6,400 triangles); the device's cluster merging makes no
-            # headway on the string of zero-area boxes and hands over to the Morton-code hierarchy (at most 95 levels, usually ~30)
-            assert 8 <= sweeps <= (64 if builder == capi.BVH_BUILDER_SAH else 96), (builder, sweeps)
+            # surface-area builders (host and device): 40 cost-driven levels, then halving (13 more for 6,400 triangles); the device's
+            # cluster merging makes no headway on the string of zero-area boxes and hands over to the Morton-code hierarchy (at most
+            # 95 levels, usually ~30)
+            assert 8 <= sweeps <= (96 if builder == capi.BVH_BUILDER_PLOC else 64), (builder, sweeps)
             t.set_accel_mode(capi.ACCEL_BVH)
             c, bi, bt = t.verify_accel(2)
             assert c >= W * H and (bi, bt) == (0, 0), (builder, eye, shading, c, bi, bt)
@@ -788,3 +790,27 @@ def test_million_triangle_crops_against_the_oracle(shading):
             assert t.stats()["rays"] == rays
 
 
+
+
+@pytest.mark.parametrize("workload,spp", [("monkeyhead2", 4), ("suzanne", 4), ("torus_distorted", 2)])
+def test_device_surface_area_builder_makes_the_host_builders_tree(workload, spp):
+    """PT_BVH_BUILDER_BINNED applies SahBuilder::split's rules on the device. Below 131,072 triangles nothing is sampled, so the two
+    builders must choose the same planes and the walks must fetch exactly the same numbers of nodes and triangle records (the
+    numbering of the wide nodes differs, the tree does not); images equal as for every builder."""
+    from pathtracer_amd import Tracer, capi
+    from pathtracer_amd.scenes import SceneData
+    scene = SceneData(workload)
+    seen = {}
+    for builder in (capi.BVH_BUILDER_SAH, capi.BVH_BUILDER_BINNED):
+        with Tracer(0) as t:
+            t.set_bvh_builder(builder)
+            scene.upload(t, shading="materials")
+            t.target_create(480, 270)
+            t.set_accel_mode(capi.ACCEL_BVH)
+            t.dispatch(1, spp, 1)
+            t.finish()
+            st = t.stats()
+            seen[builder] = (st["grid_triangle_tests"], st["lane_walk_records"], st["rays_traced"], st["bvh_sweeps"], t.readback().copy())
+    a, b = seen[capi.BVH_BUILDER_SAH], seen[capi.BVH_BUILDER_BINNED]
+    assert a[:4] == b[:4] and a[0] > 0, (a[:4], b[:4])
+    assert n_bit_mismatch(a[4], b[4]) == 0

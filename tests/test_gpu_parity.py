@@ -111,7 +111,7 @@ def in_step_walk_tracer():
     t.close()
 
 
-@pytest.mark.parametrize("accel", ["brute", "bvh", "bvh_morton", "bvh_sah", "bvh_wave"])
+@pytest.mark.parametrize("accel", ["brute", "bvh", "bvh_morton", "bvh_sah", "bvh_ploc", "bvh_wave"])
 def test_materials_mode_random_scene_against_oracle(tracer, wave_walk_tracer, accel):
     """Diffuse/emissive mode on a seeded cloud of random triangles seen from inside (rays bounce from their hit points, hit emitters,
     leave through gaps): the all-triangles loop and the LBVH walk must both equal the CPU oracle bit for bit."""
@@ -135,9 +135,9 @@ def test_materials_mode_random_scene_against_oracle(tracer, wave_walk_tracer, ac
     t = wave_walk_tracer if accel == "bvh_wave" else tracer
     prog = setup_case(t, fx)
     if accel != "brute":
-        t.set_bvh_builder({"bvh_morton": capi.BVH_BUILDER_MORTON, "bvh_sah": capi.BVH_BUILDER_SAH}.get(accel, capi.BVH_BUILDER_PLOC))
+        t.set_bvh_builder({"bvh_morton": capi.BVH_BUILDER_MORTON, "bvh_sah": capi.BVH_BUILDER_SAH, "bvh_ploc": capi.BVH_BUILDER_PLOC}.get(accel, capi.BVH_BUILDER_BINNED))
         t.build_accel()
-        t.set_bvh_builder(capi.BVH_BUILDER_PLOC)
+        t.set_bvh_builder(capi.BVH_BUILDER_BINNED)
         t.set_accel_mode(capi.ACCEL_BVH)
     else:
         t.set_accel_mode(capi.ACCEL_BRUTE)
@@ -151,7 +151,7 @@ def test_materials_mode_random_scene_against_oracle(tracer, wave_walk_tracer, ac
     ref, rays = po.render(scene, u, 1, 3, threads=8)
     assert n_bit_mismatch(img, ref) == 0
     assert st["rays"] == rays and rays > 2 * W * H * 3
-    if accel in ("bvh", "bvh_morton", "bvh_sah"):
+    if accel in ("bvh", "bvh_morton", "bvh_sah", "bvh_ploc"):
         assert st["grid_triangle_tests"] > 0 and st["bvh_node_fetches"] == 0     # per-lane walk: records counted per ray
     if accel == "bvh_wave":
         assert st["bvh_node_fetches"] > 0
@@ -213,11 +213,11 @@ def test_materials_walk_on_awkward_layouts(tracer, layout):
           "indices": idx, "spheres": sph, "materials": mats, "shading_mode": 1, "material_ids": mids}
     prog = setup_case(tracer, fx)
     images, rays = {}, {}
-    for accel in ("brute", "bvh_morton", "bvh_sah", "bvh"):
+    for accel in ("brute", "bvh_morton", "bvh_sah", "bvh_ploc", "bvh"):
         if accel != "brute":
-            tracer.set_bvh_builder({"bvh_morton": capi.BVH_BUILDER_MORTON, "bvh_sah": capi.BVH_BUILDER_SAH}.get(accel, capi.BVH_BUILDER_PLOC))
+            tracer.set_bvh_builder({"bvh_morton": capi.BVH_BUILDER_MORTON, "bvh_sah": capi.BVH_BUILDER_SAH, "bvh_ploc": capi.BVH_BUILDER_PLOC}.get(accel, capi.BVH_BUILDER_BINNED))
             tracer.build_accel()
-            tracer.set_bvh_builder(capi.BVH_BUILDER_PLOC)
+            tracer.set_bvh_builder(capi.BVH_BUILDER_BINNED)
             tracer.set_accel_mode(capi.ACCEL_BVH)
         else:
             tracer.set_accel_mode(capi.ACCEL_BRUTE)
@@ -230,9 +230,9 @@ def test_materials_walk_on_awkward_layouts(tracer, layout):
         if accel != "brute" and nt > 4:   # (up to four triangles are one leaf: pt_build_accel keeps no hierarchy and PT_ACCEL_BVH runs the loop)
             compared, bad_id, bad_t = tracer.verify_accel(3)
             assert compared >= W * H and bad_id == 0 and bad_t == 0
-    for accel in ("bvh", "bvh_morton", "bvh_sah"):
+    for accel in ("bvh", "bvh_morton", "bvh_sah", "bvh_ploc"):
         assert n_bit_mismatch(images[accel], images["brute"]) == 0, accel
-    assert rays["bvh"] == rays["bvh_morton"] == rays["bvh_sah"] == rays["brute"] > W * H * 4
+    assert rays["bvh"] == rays["bvh_morton"] == rays["bvh_sah"] == rays["bvh_ploc"] == rays["brute"] > W * H * 4
     tracer.set_accel_mode(capi.ACCEL_AUTO)
     tracer.set_shading_mode(0)
     tracer.program_destroy(prog)

@@ -19,7 +19,7 @@ def main():
     ap.add_argument("--shading", default="materials")
     ap.add_argument("--accel", default="auto")
     ap.add_argument("--lib", default=None, help="a variant library (pathtracer_amd.build.build_hip(tag=...))")
-    ap.add_argument("--builders", default="morton,sah,ploc")
+    ap.add_argument("--builders", default="morton,sah,ploc,binned")
     args = ap.parse_args()
     from pathtracer_amd import Tracer, capi
     from pathtracer_amd.scenes import SceneData
