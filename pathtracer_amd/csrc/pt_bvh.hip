@@ -31,6 +31,15 @@ __device__ __forceinline__ float ord2f(uint32_t o) {
     return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
 }
 
+// Bounds kept by atomic min / max only ever move one way, so a plain look first (however stale) tells when the atomic cannot
+// change anything: nearly always, once a few waves have been through, and then thousands of waves no longer queue on one address.
+__device__ __forceinline__ void atomic_min_if_lower(uint32_t* at, uint32_t v) {
+    if (v < *(volatile const uint32_t*)at) atomicMin(at, v);
+}
+__device__ __forceinline__ void atomic_max_if_higher(uint32_t* at, uint32_t v) {
+    if (v > *(volatile const uint32_t*)at) atomicMax(at, v);
+}
+
 __device__ __forceinline__ unsigned long long spread21(uint32_t v) {  // 21 bits -> every third bit of 63
     unsigned long long x = v & 0x1fffffu;
     x = (x | x << 32) & 0x001f00000000ffffull;
@@ -46,8 +55,7 @@ __global__ __launch_bounds__(256) void bvh_init_scene_box(uint32_t* scene_box) {
     else if (threadIdx.x < 6) scene_box[threadIdx.x] = 0u;           // max
 }
 
-// per triangle: absolute box (6 floats); scene box of the centroids by atomics (one per wave would be nicer; n is small
-// next to the render work)
+// per triangle: absolute box (6 floats); scene box of the centroids by atomics
 __global__ __launch_bounds__(256) void bvh_tri_boxes(const float* __restrict__ vertices, const uint32_t* __restrict__ indices, int n,
                                                      float* __restrict__ tri_box, uint32_t* __restrict__ scene_box) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -62,8 +70,8 @@ __global__ __launch_bounds__(256) void bvh_tri_boxes(const float* __restrict__ v
         tri_box[6 * (size_t)i + k] = lo[k];
         tri_box[6 * (size_t)i + 3 + k] = hi[k];
         const float ctr = 0.5f * lo[k] + 0.5f * hi[k];
-        atomicMin(&scene_box[k], f2ord(ctr));
-        atomicMax(&scene_box[3 + k], f2ord(ctr));
+        atomic_min_if_lower(&scene_box[k], f2ord(ctr));
+        atomic_max_if_higher(&scene_box[3 + k], f2ord(ctr));
     }
 }
 
@@ -1066,8 +1074,8 @@ __global__ __launch_bounds__(256) void sahd_bounds(const uint32_t* __restrict__ 
             const bool number = mine && s.c[k] == s.c[k];
             const uint32_t lo = wave_min_u32(number ? f2ord(s.c[k]) : 0xffffffffu), hi = wave_max_u32(number ? f2ord(s.c[k]) : 0u);
             if (lane == leader) {
-                atomicMin(&cb[6 * (size_t)r0 + k], lo);
-                atomicMax(&cb[6 * (size_t)r0 + 3 + k], hi);
+                atomic_min_if_lower(&cb[6 * (size_t)r0 + k], lo);
+                atomic_max_if_higher(&cb[6 * (size_t)r0 + 3 + k], hi);
             }
         }
         todo &= ~__builtin_amdgcn_ballot_w64(mine);
@@ -1100,8 +1108,8 @@ __global__ __launch_bounds__(256) void sahd_bins(const uint32_t* __restrict__ or
             const size_t at = (size_t)current * kDevPairs + lane;
             atomicAdd(&cnt[at], count);
             for (int k = 0; k < 3; ++k) {
-                atomicMin(&box[6 * at + k], f2ord(lo[k]));
-                atomicMax(&box[6 * at + 3 + k], f2ord(hi[k]));
+                atomic_min_if_lower(&box[6 * at + k], f2ord(lo[k]));
+                atomic_max_if_higher(&box[6 * at + 3 + k], f2ord(hi[k]));
             }
         }
         for (int k = 0; k < 3; ++k) { lo[k] = 3.0e38f; hi[k] = -3.0e38f; }
