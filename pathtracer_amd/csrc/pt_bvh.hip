@@ -1,6 +1,8 @@
-// Bounding volume hierarchy over the mesh -- built on the device (Morton codes -> radix sort -> Karras hierarchy) or, by
-// default, top-down on the host with the surface-area heuristic; boxes bottom-up on the device either way -- emitted as 64-byte
-// "two children per record" nodes for wave-coherent traversal and as four-child nodes with 16-bit boxes for the per-lane walk. The reference has no acceleration structure (its
+// Bounding volume hierarchy over the mesh -- built on the device (by default top-down with the binned surface-area heuristic;
+// or clusters merged bottom-up; or Morton codes -> radix sort -> Karras hierarchy) or top-down on the host with the same
+// surface-area rules; boxes bottom-up on the device either way -- emitted as 64-byte "two children per record" nodes for
+// wave-coherent traversal and as four-child nodes with 16-bit boxes for the per-lane walk. The reference has no acceleration
+// structure (its
 // shader loops over every triangle, pathtracing.fs:129); this one exists so that scenes far beyond a few thousand
 // triangles are traceable, and it must not change a single result: traversal (pt_kernels.hip) only ever SKIPS triangles
 // that the exact test could not accept, and resolves equal distances by the lowest triangle index, which is what the

@@ -123,8 +123,8 @@ hipError_t pt_grid_fill(const PtGridBuild& g, const float* tris, int32_t n, hipS
 size_t pt_bvh_sort_temp_bytes(int32_t n);
 // Morton codes, sort, hierarchy, boxes. Synchronises the stream (a handful of times) to learn when the refit is done.
 hipError_t pt_bvh_build_topology(const PtBvhBuild& b, hipStream_t stream, int32_t* out_passes);       // Morton codes, Karras hierarchy
-hipError_t pt_bvh_build_topology_ploc(const PtBvhBuild& b, hipStream_t stream, int32_t* out_passes);  // clusters merged along the Morton curve (default)
-hipError_t pt_bvh_build_topology_binned(const PtBvhBuild& b, hipStream_t stream, int32_t* out_passes);  // the host builder's rules on the device
+hipError_t pt_bvh_build_topology_ploc(const PtBvhBuild& b, hipStream_t stream, int32_t* out_passes);  // clusters merged along the Morton curve
+hipError_t pt_bvh_build_topology_binned(const PtBvhBuild& b, hipStream_t stream, int32_t* out_passes);  // the host builder's rules on the device (default)
 hipError_t pt_bvh_build_topology_sah(const PtBvhBuild& b, hipStream_t stream, int32_t* out_passes);   // host-side builder, same arrays
 // Traversal records for ray origin `ro` + triangle records/ids in leaf order (from the per-triangle records `tris`).
 hipError_t pt_bvh_emit(const PtBvhBuild& b, const float ro[3], const float* tris, const float* tris_abs, hipStream_t stream);
