@@ -1027,25 +1027,62 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
     // in the same trip, so lanes of a wave stay busy although their paths differ in length.
     // KIND 3 keeps all 64 lanes in the loop until the wave is done (its cull step is a wave-wide operation); the other
     // kinds simply let finished lanes drop out.
+    // Shade() of the pending hit (fs:224-361); returns whether the sample ends with it
+    auto shade_pending = [&]() -> bool {
+        if (pend_hit) {
+            ++shaded;
+            if (MATERIALS) {
+                const v3 P = ro + rd * pend_t;  // recPoint, fs:163
+                shade_materials(rng, p.materials, p.material_ids[pend_id], energy, emitted, ro, rd, P, pend_n, p.shading_mode == 2);
+            } else {
+                shade(rng, energy.x, rd, pend_n);
+            }
+        }
+        ++level;
+        const bool spent = MATERIALS ? (energy.x == 0.0f && energy.y == 0.0f && energy.z == 0.0f) : energy.x == 0.0f;
+        return !pend_hit || spent || level >= p.depth;
+    };
+    // the end of a sample (fs:408-415): folded into the pixel, and the lane's state set for its next sample
+    auto end_sample = [&]() {
+        const float t = 0.5f * (rd.y + 1.0f);
+        const float omt = 1.0f - t;
+        const float ex = energy.x, ey = MATERIALS ? energy.y : energy.x, ez = MATERIALS ? energy.z : energy.x;
+        float sr = ex * (omt + 0.5f * t), sg = ey * (omt + 0.7f * t), sb = ez * (omt + 1.0f * t);
+        if (MATERIALS) { sr = sr + emitted.x; sg = sg + emitted.y; sb = sb + emitted.z; }
+        if (scratch_slot >= 0) {
+            park(&scratch[(size_t)(sample_count - remaining) * PT_TILE_THREADS], sr, sg, sb, energy.x, rd.y);
+        } else if (p.accum_mode == 0) {
+            const float a = ieee_rcp(rng.samples);
+            mr = mr + a * (sr - mr);
+            mg = mg + a * (sg - mg);
+            mb = mb + a * (sb - mb);
+        } else {
+            mr += sr; mg += sg; mb += sb;
+        }
+        --remaining;
+        sample += p.sample_stride;
+        ro = ro0; rd = rd0; energy = V(1.0f, 1.0f, 1.0f); emitted = V(0.f, 0.f, 0.f); level = 0;
+        rng.samples = (float)sample;
+        rng.sx = 0.0f;
+        pending = reuse; pend_hit = hit0; pend_n = N0; pend_t = t0; pend_id = id0;
+    };
     while (KIND == 3 ? __builtin_amdgcn_ballot_w64(remaining > 0) != 0 : remaining > 0) {
         const bool live = remaining > 0;
         bool done = false;
         if (live && p.depth <= 0) {
             done = true;
         } else if (live && pending) {
-            if (pend_hit) {
-                ++shaded;
-                if (MATERIALS) {
-                    const v3 P = ro + rd * pend_t;  // recPoint, fs:163
-                    shade_materials(rng, p.materials, p.material_ids[pend_id], energy, emitted, ro, rd, P, pend_n, p.shading_mode == 2);
-                } else {
-                    shade(rng, energy.x, rd, pend_n);
-                }
-            }
-            ++level;
-            const bool spent = MATERIALS ? (energy.x == 0.0f && energy.y == 0.0f && energy.z == 0.0f) : energy.x == 0.0f;
-            done = !pend_hit || spent || level >= p.depth;
+            done = shade_pending();
         }
+#ifdef PT_V_RESHADE
+        // measurement build: a lane whose sample ended in Shade() has no ray for this trip's closest-hit part; here it folds the
+        // sample at once and shades its next sample's reused camera-ray hit, so that it enters that part with a ray
+        if (KIND == 1 && MATERIALS && reuse && live && done && p.depth > 0) {
+            end_sample();
+            if (remaining <= 0) continue;
+            done = shade_pending();
+        }
+#endif
         const bool want = live && !done;
         if (KIND == 3 || want) pend_hit = intersect(ro, rd, want, pend_n, pend_t, pend_id);
         if (__builtin_amdgcn_ballot_w64(want)) ++trips;
@@ -1054,30 +1091,7 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
             pending = true;
             done = !pend_hit;  // a miss ends the sample in this same trip
         }
-        if (live && done) {
-            // fs:408-415
-            const float t = 0.5f * (rd.y + 1.0f);
-            const float omt = 1.0f - t;
-            const float ex = energy.x, ey = MATERIALS ? energy.y : energy.x, ez = MATERIALS ? energy.z : energy.x;
-            float sr = ex * (omt + 0.5f * t), sg = ey * (omt + 0.7f * t), sb = ez * (omt + 1.0f * t);
-            if (MATERIALS) { sr = sr + emitted.x; sg = sg + emitted.y; sb = sb + emitted.z; }
-            if (scratch_slot >= 0) {
-                park(&scratch[(size_t)(sample_count - remaining) * PT_TILE_THREADS], sr, sg, sb, energy.x, rd.y);
-            } else if (p.accum_mode == 0) {
-                const float a = ieee_rcp(rng.samples);
-                mr = mr + a * (sr - mr);
-                mg = mg + a * (sg - mg);
-                mb = mb + a * (sb - mb);
-            } else {
-                mr += sr; mg += sg; mb += sb;
-            }
-            --remaining;
-            sample += p.sample_stride;
-            ro = ro0; rd = rd0; energy = V(1.0f, 1.0f, 1.0f); emitted = V(0.f, 0.f, 0.f); level = 0;
-            rng.samples = (float)sample;
-            rng.sx = 0.0f;
-            pending = reuse; pend_hit = hit0; pend_n = N0; pend_t = t0; pend_id = id0;
-        }
+        if (live && done) end_sample();
     }
     if (in_window && scratch_slot < 0) {
         const float alpha = p.accum_mode == 0 ? 1.0f : prev.w + (float)p.num_samples;

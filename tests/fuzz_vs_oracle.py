@@ -102,6 +102,7 @@ def main(argv=None):
         first0 = int(rng.integers(1, 50))
         stride = 1 if mean else int(rng.integers(1, 9))
         counts = [int(rng.choice([1, 2, 7, 33, 96])) for _ in range(int(rng.integers(1, 4)))]
+        builder = int(rng.choice([capi.BVH_BUILDER_BINNED, capi.BVH_BUILDER_BINNED, capi.BVH_BUILDER_PLOC, capi.BVH_BUILDER_MORTON, capi.BVH_BUILDER_SAH]))
         if args.only >= 0 and case != args.only:
             continue
         prog = t.program_create(kind)
@@ -118,6 +119,7 @@ def main(argv=None):
         t.target_create(W, H)
         t.set_uniforms(cam, ntri, depth)
         if kind == 1:
+            t.set_bvh_builder(builder)
             t.build_accel()
         t.set_accel_mode(accel)
         if window:
@@ -183,7 +185,7 @@ def main(argv=None):
         bad_cases += 0 if ok else 1
         total_rays += int(st["rays"])
         print(json.dumps({"case": case, "scene": str(pick) if kind else "spheres", "triangles": ntri, "size": [W, H], "window": window,
-                          "interleave": interleave, "depth": depth, "shading": "materials" if materials_mode else "reference", "accel": accel, "reuse": reuse, "mean": mean, "stride": stride, "dispatches": plan,
+                          "interleave": interleave, "depth": depth, "shading": "materials" if materials_mode else "reference", "accel": accel, "builder": builder, "reuse": reuse, "mean": mean, "stride": stride, "dispatches": plan,
                           "differing_words": diff, "nan_words": int(both_nan.sum()), "differing_ids": id_diff, "differing_t": t_diff, "ray_count_difference": ray_diff}),
               flush=True)
         if args.only >= 0:

@@ -26,6 +26,7 @@ VARIANTS = {
     "countfull": ["-DPT_V_COUNT_FULL"],  # all-triangles loops: counts the tests past the wave-uniform back-face skip (tools/pmc_collect.py uses it)
     "split07": ["-DPT_V_SPREAD_SPLIT=0.7f"],   # split factor of spread-out views 0.7 / 1 instead of 0.85
     "split1": ["-DPT_V_SPREAD_SPLIT=1.0f"],
+    "reshade": ["-DPT_V_RESHADE"],   # materials loop: a lane whose sample ended in Shade() shades its next sample's camera hit in the same trip
     "iters": ["-DPT_V_COUNT_ITERS"],   # direction grid: list-loop trips per wave in bvh_node_fetches, lanes with >1 test in bvh_triangle_fetches
 }
 
@@ -57,6 +58,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--only", default=None)
     ap.add_argument("--accel", type=int, default=0, help="0 auto, 1 brute, 2 bvh, 3 cull")
+    ap.add_argument("--shading", default="reference")
     args = ap.parse_args()
     from pathtracer_amd import build as ptbuild
     names = [v for v in VARIANTS if not args.only or v in args.only.split(",")]
@@ -74,7 +76,7 @@ def main():
     tracers, ref = {}, None
     for v in names:
         t = Tracer(0, os.path.join(ROOT, "pathtracer_amd", "lib", f"libpt_hip__{v}.so"))
-        scene.upload(t, accel=(args.accel in (0, 2)))
+        scene.upload(t, accel=(args.accel in (0, 2)), shading=args.shading)
         t.set_accel_mode(args.accel)
         t.target_create(scene.width, scene.height)
         t.enable_timing(True)
