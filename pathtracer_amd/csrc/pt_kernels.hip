@@ -218,7 +218,7 @@ __device__ __forceinline__ void test_triangle(const TriRec& t, int id, v3 rd, Hi
 // shader's commented line fs:274 does): fs:136-168 as written, from a record that holds a, e1, e2 and the triangle's
 // material id:  a.xyz e1.x | e1.yz e2.xy | e2.z matid - - | -
 template <bool ANY_ORDER>
-__device__ __forceinline__ void test_triangle_from(const TriRec& t, int id, v3 ro, v3 rd, Hit& h, unsigned& full) {
+__device__ __forceinline__ void test_triangle_from(const TriRec& t, int id, v3 ro, v3 rd, Hit& h, unsigned& full, bool* accepted = nullptr) {
     const v3 a = V(t.a.x, t.a.y, t.a.z);
     const v3 e1 = V(t.a.w, t.b.x, t.b.y);
     const v3 e2 = V(t.b.z, t.b.w, t.c.x);
@@ -237,6 +237,7 @@ __device__ __forceinline__ void test_triangle_from(const TriRec& t, int id, v3 r
         const float ood = ieee_rcp(det);
         const float tt = dot3(e2, r) * ood;
         const bool closer = ANY_ORDER ? (tt < h.t || (tt == h.t && id < h.id)) : (tt < h.t);
+        if (accepted && tt > 0.0f) *accepted = true;   // (measurement builds)
         if (tt > 0.0f && closer) {
             h.t = tt; h.id = id; h.u = u; h.v = v; h.ood = ood;
         }
@@ -303,6 +304,21 @@ __device__ __forceinline__ Hit intersect_mesh_from(const float* __restrict__ tri
     Hit h;
     h.t = 1.0e38f; h.id = -1; h.u = 0.f; h.v = 0.f; h.ood = 0.f;
     const float4* __restrict__ recs = reinterpret_cast<const float4*>(tris_abs);
+#ifdef PT_V_GROUP_COUNT
+    // measurement build: how often NO lane of the wave has a ray that any of 12 consecutive triangles accepts (whatever its
+    // distance) -- the most a wave-uniform skip of that group by a box around it could save; counted in `full`
+    bool any = false;
+    for (int i = 0; i < n; ++i) {
+        const TriRec t = load_rec(recs, i);
+        unsigned unused = 0;
+        test_triangle_from<false>(t, i, ro, rd, h, unused, &any);
+        if (i % 12 == 11 || i == n - 1) {
+            if (!__builtin_amdgcn_ballot_w64(any)) ++full;
+            any = false;
+        }
+    }
+    return h;
+#else
     TriRec a0 = load_rec(recs, 0), a1 = load_rec(recs, 1);
     for (int i = 0; i < n; i += 4) {
         const TriRec b0 = load_rec(recs, i + 2), b1 = load_rec(recs, i + 3);
@@ -314,6 +330,7 @@ __device__ __forceinline__ Hit intersect_mesh_from(const float* __restrict__ tri
         test_triangle_from<false>(b1, i + 3, ro, rd, h, full);
     }
     return h;
+#endif
 }
 
 // Wave-wide sum / max of a value held by ALL 64 lanes (EXEC must be full), without LDS: two quad permutes and two row
