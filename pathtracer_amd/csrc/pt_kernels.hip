@@ -719,81 +719,6 @@ __device__ __forceinline__ Hit intersect_grid(const PtKernelParams& p, v3 rd, bo
     return h;
 }
 
-#ifdef PT_V_CARRY
-#ifndef PT_CARRY_MIN_LANES
-#define PT_CARRY_MIN_LANES 8
-#endif
-__device__ __forceinline__ v3 mesh_normal(const PtKernelParams& p, const Hit& h);
-// The direction-grid query in two pieces, for the variant in which a lane tests ONE triangle of its cell's list per trip of the
-// render loop and carries the rest of the list into the next trip (instead of the wave running its list loop as long as its
-// longest list). grid_lookup: the first entry of the cell's list (top bit = last) and its position; false when the cell is empty.
-__device__ __forceinline__ bool grid_lookup(const PtKernelParams& p, v3 rd, bool want, bool use_occ, uint32_t& entry, uint32_t& pos) {
-    const CubeCoords cc = cube_coords(rd);
-    const float fw2 = __builtin_fabsf(cc.ma);
-    entry = PT_GRID_EMPTY;
-    if (want && fw2 > 0.f) {
-        const float iw2 = __builtin_amdgcn_rcpf(fw2);
-        const int res = p.grid_res;
-        const float fres = (float)res;
-        const uint32_t face = (uint32_t)cc.id;
-        int iu = (int)__builtin_floorf((cc.sc * iw2 + 0.5f) * fres), iv = (int)__builtin_floorf((cc.tc * iw2 + 0.5f) * fres);
-        asm("v_med3_i32 %0, %1, 0, %2" : "=v"(iu) : "v"(iu), "s"(res - 1));
-        asm("v_med3_i32 %0, %1, 0, %2" : "=v"(iv) : "v"(iv), "s"(res - 1));
-        const uint32_t cell = __umul24(__umul24(face, (uint32_t)res) + (uint32_t)iv, (uint32_t)res) + (uint32_t)iu;
-        bool look = true;
-        if (use_occ) {
-            const uint32_t edge = (uint32_t)PT_GRID_OCC_EDGE(res);
-            const uint32_t blk = __umul24(__umul24(face, edge) + ((uint32_t)iv >> 2), edge) + ((uint32_t)iu >> 2);
-            look = ((p.grid_occ[blk >> 5] >> (blk & 31u)) & 1u) != 0u;
-        }
-        if (look) entry = grid_word(p.grid_cells, cell);
-    }
-    const bool more = entry != PT_GRID_EMPTY;
-    pos = 0u;
-    if (more) {
-        if (entry & 0x80000000u) {
-            pos = entry & 0x7fffffffu;
-            entry = grid_word(p.grid_list, pos);
-        } else {
-            entry |= 0x80000000u;
-        }
-    }
-    return more;
-}
-// grid_test_one: the exact test of the list's current triangle against the best hit so far (t, id, normal); returns whether the
-// list goes on (entry / pos then name the next triangle).
-__device__ __forceinline__ bool grid_test_one(const PtKernelParams& p, v3 rd, uint32_t& entry, uint32_t& pos, float& best_t, int& best_id, v3& best_n,
-                                              float* __restrict__ uvo, unsigned& tests) {
-    const uint32_t tri = entry & 0x7fffffffu;
-    const bool last = (entry & 0x80000000u) != 0u;
-    if (!last) entry = grid_word(p.grid_list, ++pos);
-    const float4* __restrict__ rec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.grid_tris) + (tri << 6));
-    TriRec t;
-    t.a = rec[0]; t.b = rec[1]; t.c = rec[2]; t.d = rec[3];
-    const v3 e1 = V(t.a.x, t.a.y, t.a.z);
-    const v3 e2 = V(t.a.w, t.b.x, t.b.y);
-    const v3 q = cross3(rd, e2);
-    const float det = dot3(e1, q);
-    const v3 ap = V(t.b.z, t.b.w, t.c.x);
-    const v3 r = V(t.c.y, t.c.z, t.c.w);
-    const float u = dot3(ap, q);
-    const float v = dot3(rd, r);
-    asm volatile("" : "+v"(t.d.x), "+v"(t.d.y), "+v"(t.d.z), "+v"(t.d.w));
-    if ((det >= 0.0001f) & (u >= 0.0f) & (v >= 0.0f) & ((u + v) <= det)) {
-        const float ood = ieee_rcp(det);
-        const float tt = t.d.x * ood;
-        if (tt > 0.0f && (tt < best_t || (tt == best_t && (int)tri < best_id))) {
-            best_t = tt; best_id = (int)tri;
-            best_n = V(t.d.y, t.d.z, t.d.w);
-            // what the interpolated normal needs, should this stay the hit (formed when the query is answered): parked in LDS
-            if (p.normal_mode == 0) { uvo[0] = u; uvo[64] = v; uvo[128] = ood; }
-        }
-    }
-    ++tests;
-    return !last;
-}
-#endif
-
 // fs:83-121. The ray origin is the camera position for every ray, so the terms of the sphere test that do not involve the
 // direction are taken from a per-sphere record made once per camera position (pt_prepare_spheres_kernel: to = ro - centre,
 // C = dot(to, to) - r*r, 1/r; the same fp32 operations the shader performs per ray). The normal (fs:111) is formed once,
@@ -1158,52 +1083,6 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
         rng.sx = 0.0f;
         pending = reuse; pend_hit = hit0; pend_n = N0; pend_t = t0; pend_id = id0;
     };
-#ifdef PT_V_CARRY
-    // variant of the loop for the direction grid: one triangle test per trip; a lane whose cell lists more carries the rest of the
-    // list (entry, position; best hit so far in pend_t / pend_id / pend_n) into the next trip and shades one trip later
-    if (KIND == 4) {
-        __shared__ float s_uvo[PT_TILE_WAVES][3 * 64];
-        float* __restrict__ uvo = &s_uvo[threadIdx.x >> 6][threadIdx.x & 63];
-        uint32_t carry_entry = 0u, carry_pos = 0u;
-        bool listing = false;
-        while (remaining > 0) {
-            bool done = false;
-            if (!listing) {
-                if (p.depth <= 0) done = true;
-                else if (pending) done = shade_pending();
-            }
-            const bool want = !listing && !done;
-            bool more = listing;
-            if (want) {
-                more = grid_lookup(p, rd, true, use_occ, carry_entry, carry_pos);
-                pend_t = 1.0e38f; pend_id = -1;
-                ++traced;
-            }
-            const int querying = __builtin_popcountll(__builtin_amdgcn_ballot_w64(want || listing));
-            if (querying) ++trips;
-            // One test for every lane that has one to do; further rounds while many lanes have more: a carried list costs its lane
-            // a trip, i.e. the wave about lanes-that-carry / lanes-with-a-query of a trip (lanes whose pixel sees only sky end a
-            // sample per trip and never hold the wave up), a round costs the wave one triangle test, about an eighth of a trip.
-            for (bool first = true;; first = false) {
-                const unsigned long long carrying = __builtin_amdgcn_ballot_w64(more);
-                if (!carrying || (!first && __builtin_popcountll(carrying) * PT_CARRY_MIN_LANES < querying)) break;
-                if (more) more = grid_test_one(p, rd, carry_entry, carry_pos, pend_t, pend_id, pend_n, uvo, lane_tests);
-            }
-            if ((want || listing) && !more) {   // the query is answered
-                pend_hit = pend_id >= 0;
-                if (pend_hit && p.normal_mode == 0) {
-                    Hit h;
-                    h.t = pend_t; h.id = pend_id; h.u = uvo[0]; h.v = uvo[64]; h.ood = uvo[128];
-                    pend_n = mesh_normal(p, h);
-                }
-                pending = true;
-                done = !pend_hit;
-            }
-            listing = more;
-            if (done) end_sample();
-        }
-    } else
-#endif
     while (KIND == 3 ? __builtin_amdgcn_ballot_w64(remaining > 0) != 0 : remaining > 0) {
         const bool live = remaining > 0;
         bool done = false;

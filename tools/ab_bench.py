@@ -26,8 +26,6 @@ VARIANTS = {
     "countfull": ["-DPT_V_COUNT_FULL"],  # all-triangles loops: counts the tests past the wave-uniform back-face skip (tools/pmc_collect.py uses it)
     "split07": ["-DPT_V_SPREAD_SPLIT=0.7f"],   # split factor of spread-out views 0.7 / 1 instead of 0.85
     "split1": ["-DPT_V_SPREAD_SPLIT=1.0f"],
-    "carry": ["-DPT_V_CARRY"],
-    "carry6": ["-DPT_V_CARRY", "-DPT_CARRY_MIN_LANES=6"], "carry12": ["-DPT_V_CARRY", "-DPT_CARRY_MIN_LANES=12"], "carry8": ["-DPT_V_CARRY", "-DPT_CARRY_MIN_LANES=8"], "carry16": ["-DPT_V_CARRY", "-DPT_CARRY_MIN_LANES=16"],   # direction grid: one triangle test per trip, the rest of a cell's list carried into the next trip
     "reshade": ["-DPT_V_RESHADE"],   # materials loop: a lane whose sample ended in Shade() shades its next sample's camera hit in the same trip
     "iters": ["-DPT_V_COUNT_ITERS"],   # direction grid: list-loop trips per wave in bvh_node_fetches, lanes with >1 test in bvh_triangle_fetches
 }
