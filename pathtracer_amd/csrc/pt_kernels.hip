@@ -1168,13 +1168,17 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
 // A lane that finishes a walk early goes on to its next bounce while its neighbours are still walking. The image is the
 // one pt_render_kernel<5, true> renders (and the all-triangles loop, and the shader): per pixel the samples are still folded
 // in order by the lane that owns the pixel.
+// lanes that wait before the wave shades (over the surface-area hierarchy, with 2 node steps per round; 1M triangles / 3,936 / 968 /
+// the torus pair: 16: 8.21 / 4.73 / 2.93 / 5.07 ms, 24: 8.26 / 4.65 / 2.84 / 4.87, 32: 8.38 / 4.72 / 2.89 / 4.77)
 #ifndef PT_SHADE_BATCH
-#define PT_SHADE_BATCH 16
+#define PT_SHADE_BATCH 24
 #endif
-// node steps per round before the lane looks at its leaf (four-child nodes, 1M triangles / 3,936 / 968: 2 steps 11.9 / 5.74 /
-// 3.63 ms, 3: 11.8 / 5.74 / 3.71, 8: 13.2 / 6.90 / 4.13)
+// node steps per round before the lane looks at its leaf. Over the Morton-code hierarchy the time was flat between 2 and 3 (1M
+// triangles / 3,936 / 968: 2 steps 11.9 / 5.74 / 3.63 ms, 3: 11.8 / 5.74 / 3.71, 8: 13.2 / 6.90 / 4.13); over the surface-area
+// hierarchy, whose walks are shorter, 2 is better (1: 8.87 / 4.80 / 2.93, 2: 8.21 / 4.73 / 2.93, 3: 8.38 / 4.99 / 3.12, 4: 8.69 /
+// 5.17 / 3.33)
 #ifndef PT_WALK_NODE_STEPS
-#define PT_WALK_NODE_STEPS 3
+#define PT_WALK_NODE_STEPS 2
 #endif
 
 struct LaneWalk {
