@@ -29,6 +29,7 @@ VARIANTS = {
     # tuning of the decoupled walk (materials mode through the hierarchy)
     "leaf1": ["-DPT_BVH_WIDE_LEAF_MAX=1"], "leaf4": ["-DPT_BVH_WIDE_LEAF_MAX=4"], "steps1": ["-DPT_WALK_NODE_STEPS=1"], "steps2": ["-DPT_WALK_NODE_STEPS=2"], "steps2b24": ["-DPT_WALK_NODE_STEPS=2", "-DPT_SHADE_BATCH=24"],
     "steps2b32": ["-DPT_WALK_NODE_STEPS=2", "-DPT_SHADE_BATCH=32"], "steps4": ["-DPT_WALK_NODE_STEPS=4"],
+    "waves4": ["-DPT_DECOUPLED_MIN_WAVES=4"], "waves6": ["-DPT_DECOUPLED_MIN_WAVES=6"],
     "batch12": ["-DPT_SHADE_BATCH=12"], "batch24": ["-DPT_SHADE_BATCH=24"],
     "reshade": ["-DPT_V_RESHADE"],   # materials loop: a lane whose sample ended in Shade() shades its next sample's camera hit in the same trip
     "iters": ["-DPT_V_COUNT_ITERS"],   # direction grid: list-loop trips per wave in bvh_node_fetches, lanes with >1 test in bvh_triangle_fetches
