@@ -140,8 +140,8 @@ def which_kernel(st, program, shading):
         if st["bvh_node_fetches"] > 0:
             return "pt_render_kernel<2,true>", "wave_walk"
         return "pt_render_kernel<1,true>", "loop_from"
-    if st["grid_triangle_tests"] > 0:
-        return "pt_render_kernel<4,false>", "grid"
+    if st["grid_triangle_tests"] > 0:   # (the two forms of the loop do the same arithmetic: one flop table)
+        return ("pt_render_kernel<7,false>" if st.get("grid_lists_carried") else "pt_render_kernel<4,false>"), "grid"
     if st["bvh_node_fetches"] > 0:
         return "pt_render_kernel<2,false>", "wave_walk"
     return "pt_render_kernel<1,false>", "loop"

@@ -143,7 +143,10 @@ typedef struct PtStats {
     double total_dispatch_ms;  /* sum over dispatches since the last reset; 0 unless timing is enabled */
     uint32_t bvh_sweeps;       /* bottom-up sweeps the last pt_build_accel ran to box its hierarchy, a multiple of 8: an upper bound
                                   of the hierarchy's height (0 = no hierarchy) */
-    uint32_t reserved;
+    uint32_t grid_lists_carried; /* direction grid: which form of the render loop the last dispatch through the grid used. 0: the
+                                  wave runs its list loop as often as its longest list; 1: a lane tests one triangle per trip and
+                                  carries the rest of its cell's list into the next. Same image; the library times both on a
+                                  view's first long dispatches and keeps the quicker (the field was reserved before ABI 6) */
 } PtStats;
 
 typedef struct PtContext PtContext; /* opaque */

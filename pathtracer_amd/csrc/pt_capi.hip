@@ -144,6 +144,19 @@ struct PtContext {
     bool grid_use_occ = false;       // the block bits are worth a look: a quarter of the blocks or more are empty (build_grid)
     uint32_t* d_grid_occ_flag = nullptr;  // ... and the view's queries mostly miss (device word, kept up to date with the work list)
     int grid_occ_override = -1;      // PT_GRID_OCC=0/1 (experiments)
+    // The direction-grid kernel has two forms of its loop (pt_render_kernel<4 / 7, false>: the wave runs its list loop as often as its
+    // longest list / a lane tests one triangle per trip and carries the rest of its list into the next). Same image; which is
+    // quicker depends on the view (Cornell and the 1M triangles: the second by 6-11 %; the two heads: the first by 4-9 %) in a way
+    // no statistic of the queries predicted, so a view's first long dispatches with a work list time one form each (kernel time per
+    // sample, two events around the launch) and the quicker one is kept until the grid is rebuilt.
+    int grid_carry_override = -1;    // PT_GRID_CARRY=0/1 (experiments, tests): never / always the second form
+    bool grid_carry = false;         // the form in use
+    bool last_grid_carry = false;    // ... by the last dispatch that went through the grid (PtStats::grid_lists_carried)
+    int carry_trial = 0;             // 0 none yet, 1 first form being timed, 2 second form run once untimed (a kernel's first launch pays for
+                                     // its loading), 3 second form being timed, 4 decided
+    double carry_trial_ms[2] = {0.0, 0.0};   // kernel ms per sample of the two forms
+    int carry_trial_samples = 0;     // samples of the dispatch being timed
+    hipEvent_t ev_trial[2] = {nullptr, nullptr};
     unsigned long long* d_grid_count_scratch = nullptr;   // scratch of the grid's count pass and its three-word summary
     unsigned long long* h_grid_summary = nullptr;    // pinned host copy of the summary
 
@@ -440,6 +453,9 @@ PtStatus build_grid(PtContext* ctx) {
         ctx->grid_use_occ = ctx->grid_occ_override >= 0 ? ctx->grid_occ_override != 0 : 4ull * ctx->h_grid_summary[3] >= blocks;
         // until the view's own statistics say otherwise (PT_GRID_OCC=1 pins it)
         PT_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ctx->d_grid_occ_flag), 1u, 1, ctx->stream));
+        // (a new grid: which form of the render loop suits the view is found out again)
+        ctx->grid_carry = ctx->grid_carry_override > 0;
+        ctx->carry_trial = ctx->grid_carry_override >= 0 ? 4 : 0;
     }
     ctx->grid_entries = entries;
     ctx->grid_built = true;
@@ -759,6 +775,8 @@ PtStatus pt_create(int32_t device, PtContext** out_ctx) {
     if (err == hipSuccess) err = hipMalloc(&ctx->d_sphere_recs, 80 * sizeof(float));
     if (err == hipSuccess) err = hipEventCreate(&ctx->ev_start);
     if (err == hipSuccess) err = hipEventCreate(&ctx->ev_stop);
+    if (err == hipSuccess) err = hipEventCreate(&ctx->ev_trial[0]);
+    if (err == hipSuccess) err = hipEventCreate(&ctx->ev_trial[1]);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&ctx->ev_static, hipEventDisableTiming);
     if (err != hipSuccess) {
         pt_destroy(ctx);
@@ -779,6 +797,7 @@ PtStatus pt_create(int32_t device, PtContext** out_ctx) {
     if (const char* g = getenv("PT_CAMERA_RAY_GRID")) ctx->camera_ray_grid = g[0] != '0';
     if (const char* g = getenv("PT_PRIMARY_CACHE")) ctx->primary_cache_enabled = g[0] != '0';
     if (const char* g = getenv("PT_GRID_OCC")) ctx->grid_occ_override = atoi(g) != 0;
+    if (const char* g = getenv("PT_GRID_CARRY")) ctx->grid_carry_override = atoi(g) != 0;
     if (const char* g = getenv("PT_GRID_QUEUE")) ctx->grid_queue_override = atoi(g);
     if (const char* g = getenv("PT_GRID_FINE_AFTER")) ctx->grid_fine_after = atof(g);
     if (const char* g = getenv("PT_FAIL_GRID_ALLOC")) ctx->fail_grid_alloc = atoi(g);
@@ -813,6 +832,8 @@ PtStatus pt_destroy(PtContext* ctx) {
     if (ctx->d_grid_occ_flag) (void)hipFree(ctx->d_grid_occ_flag);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    for (hipEvent_t e : ctx->ev_trial)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return PT_OK;
@@ -1356,7 +1377,36 @@ PtStatus end_pass(PtContext* ctx, PtKernelParams& p, const Program* prog, int32_
         ctx->primary_cache_key = key;
         ctx->primary_cache_valid = true;  // (this dispatch writes every pixel of the window it does not read)
     }
+    // Which form of the direction-grid kernel's loop: a view's first long dispatches that run from a work list time one form each.
+    bool timed = false;
+    if (p.grid_cells && p.shading_mode == 0 && prog->kind == PT_PROGRAM_MESH) {
+        // (a list built from a probe's few samples balances worse than the later ones: such a dispatch is not compared with those)
+        if (ctx->carry_trial < 4 && p.items != nullptr && num_samples >= 16 && ctx->list_basis >= 16 && !ctx->no_alloc) {
+            if (ctx->carry_trial == 1 || ctx->carry_trial == 3) {   // the form timed by the previous such dispatch
+                float ms = 0.f;
+                PT_HIP_TRY(hipEventSynchronize(ctx->ev_trial[1]));
+                PT_HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_trial[0], ctx->ev_trial[1]));
+                ctx->carry_trial_ms[ctx->carry_trial == 1 ? 0 : 1] = (double)ms / (double)ctx->carry_trial_samples;
+            }
+            if (ctx->carry_trial == 3) {
+                ctx->grid_carry = ctx->carry_trial_ms[1] < 0.98 * ctx->carry_trial_ms[0];
+                ctx->carry_trial = 4;
+                if (getenv("PT_DEBUG_SCHED"))
+                    fprintf(stderr, "[pt grid] kernel ms per sample: list loop per wave %.5f, list remainders carried %.5f -> %s\n", ctx->carry_trial_ms[0],
+                            ctx->carry_trial_ms[1], ctx->grid_carry ? "carried" : "loop");
+            } else {
+                ctx->grid_carry = ctx->carry_trial >= 1;   // 0: the first form now; 1, 2: the second
+                timed = ctx->carry_trial != 1;             // (its first run is not timed)
+                ctx->carry_trial += 1;
+                ctx->carry_trial_samples = num_samples;
+            }
+        }
+        p.grid_carry = ctx->grid_carry ? 1 : 0;
+        ctx->last_grid_carry = ctx->grid_carry;
+    }
+    if (timed) PT_HIP_TRY(hipEventRecord(ctx->ev_trial[0], ctx->stream));
     PT_HIP_TRY(pt_launch_render(p, (int)prog->kind, ctx->stream));
+    if (timed) PT_HIP_TRY(hipEventRecord(ctx->ev_trial[1], ctx->stream));
     ctx->current ^= 1;  // PathTracer.cpp:1493
     uint64_t rows = (uint64_t)ctx->win[3];
     if (ctx->row_count > 1) {  // rows of the window that belong to this renderer
@@ -1664,7 +1714,7 @@ PtStatus pt_get_stats(PtContext* ctx, PtStats* out) {
     }
     out->dispatches = ctx->dispatches;
     out->bvh_sweeps = ctx->bvh_built ? (uint32_t)ctx->bvh_refit_passes : 0u;
-    out->reserved = 0u;
+    out->grid_lists_carried = ctx->last_grid_carry ? 1u : 0u;
     out->last_dispatch_ms = ctx->last_ms;
     out->total_dispatch_ms = ctx->total_ms;
     return PT_OK;

@@ -174,6 +174,8 @@ struct PtKernelParams {
     const uint32_t* grid_list;          // triangle indices of the cells with two or more (last one of a cell: top bit set)
     const uint32_t* grid_occ;           // one bit per 4x4 block of cells (0 = no triangle in the block), or null = not consulted
     const uint32_t* grid_occ_flag;      // device word: nonzero = queries look at grid_occ first (pt_launch_grid_occ_flag keeps it)
+    int32_t grid_carry;                 // nonzero: the render loop tests one triangle per trip and carries the rest of a cell's list into the next
+                                        // (pt_render_kernel<7, false>; the host picks the form that was quicker on this view)
     const float* grid_tris;             // per triangle: e1, e2, ap, r, e2r, geometric normal (origin-relative)
     int32_t grid_res;
     const uint32_t* live_count;         // device scalar: records in `tris` when it is the compacted array; null = num_triangles

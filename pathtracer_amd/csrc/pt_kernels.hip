@@ -719,6 +719,76 @@ __device__ __forceinline__ Hit intersect_grid(const PtKernelParams& p, v3 rd, bo
     return h;
 }
 
+__device__ __forceinline__ v3 mesh_normal(const PtKernelParams& p, const Hit& h);
+// The direction-grid query in two pieces, for the form of the render loop in which a lane tests ONE triangle of its cell's list
+// per trip and carries the rest of the list into its next trip (instead of the wave running its list loop as often as its
+// longest list). grid_lookup: the first entry of the cell's list (top bit = last) and its position; false when the cell is empty.
+__device__ __forceinline__ bool grid_lookup(const PtKernelParams& p, v3 rd, bool want, bool use_occ, uint32_t& entry, uint32_t& pos) {
+    const CubeCoords cc = cube_coords(rd);
+    const float fw2 = __builtin_fabsf(cc.ma);
+    entry = PT_GRID_EMPTY;
+    if (want && fw2 > 0.f) {
+        const float iw2 = __builtin_amdgcn_rcpf(fw2);
+        const int res = p.grid_res;
+        const float fres = (float)res;
+        const uint32_t face = (uint32_t)cc.id;
+        int iu = (int)__builtin_floorf((cc.sc * iw2 + 0.5f) * fres), iv = (int)__builtin_floorf((cc.tc * iw2 + 0.5f) * fres);
+        asm("v_med3_i32 %0, %1, 0, %2" : "=v"(iu) : "v"(iu), "s"(res - 1));
+        asm("v_med3_i32 %0, %1, 0, %2" : "=v"(iv) : "v"(iv), "s"(res - 1));
+        const uint32_t cell = __umul24(__umul24(face, (uint32_t)res) + (uint32_t)iv, (uint32_t)res) + (uint32_t)iu;
+        bool look = true;
+        if (use_occ) {
+            const uint32_t edge = (uint32_t)PT_GRID_OCC_EDGE(res);
+            const uint32_t blk = __umul24(__umul24(face, edge) + ((uint32_t)iv >> 2), edge) + ((uint32_t)iu >> 2);
+            look = ((p.grid_occ[blk >> 5] >> (blk & 31u)) & 1u) != 0u;
+        }
+        if (look) entry = grid_word(p.grid_cells, cell);
+    }
+    const bool more = entry != PT_GRID_EMPTY;
+    pos = 0u;
+    if (more) {
+        if (entry & 0x80000000u) {
+            pos = entry & 0x7fffffffu;
+            entry = grid_word(p.grid_list, pos);
+        } else {
+            entry |= 0x80000000u;
+        }
+    }
+    return more;
+}
+// grid_test_one: the exact test of the list's current triangle against the best hit so far (t, id, normal); returns whether the
+// list goes on (entry / pos then name the next triangle).
+__device__ __forceinline__ bool grid_test_one(const PtKernelParams& p, v3 rd, uint32_t& entry, uint32_t& pos, float& best_t, int& best_id, v3& best_n,
+                                              float* __restrict__ uvo, unsigned& tests) {
+    const uint32_t tri = entry & 0x7fffffffu;
+    const bool last = (entry & 0x80000000u) != 0u;
+    if (!last) entry = grid_word(p.grid_list, ++pos);
+    const float4* __restrict__ rec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.grid_tris) + (tri << 6));
+    TriRec t;
+    t.a = rec[0]; t.b = rec[1]; t.c = rec[2]; t.d = rec[3];
+    const v3 e1 = V(t.a.x, t.a.y, t.a.z);
+    const v3 e2 = V(t.a.w, t.b.x, t.b.y);
+    const v3 q = cross3(rd, e2);
+    const float det = dot3(e1, q);
+    const v3 ap = V(t.b.z, t.b.w, t.c.x);
+    const v3 r = V(t.c.y, t.c.z, t.c.w);
+    const float u = dot3(ap, q);
+    const float v = dot3(rd, r);
+    asm volatile("" : "+v"(t.d.x), "+v"(t.d.y), "+v"(t.d.z), "+v"(t.d.w));
+    if ((det >= 0.0001f) & (u >= 0.0f) & (v >= 0.0f) & ((u + v) <= det)) {
+        const float ood = ieee_rcp(det);
+        const float tt = t.d.x * ood;
+        if (tt > 0.0f && (tt < best_t || (tt == best_t && (int)tri < best_id))) {
+            best_t = tt; best_id = (int)tri;
+            best_n = V(t.d.y, t.d.z, t.d.w);
+            // what the interpolated normal needs, should this stay the hit (formed when the query is answered): parked in LDS
+            if (p.normal_mode == 0) { uvo[0] = u; uvo[64] = v; uvo[128] = ood; }
+        }
+    }
+    ++tests;
+    return !last;
+}
+
 // fs:83-121. The ray origin is the camera position for every ray, so the terms of the sphere test that do not involve the
 // direction are taken from a per-sphere record made once per camera position (pt_prepare_spheres_kernel: to = ro - centre,
 // C = dot(to, to) - r*r, 1/r; the same fp32 operations the shader performs per ray). The normal (fs:111) is formed once,
@@ -872,11 +942,12 @@ __device__ __forceinline__ bool work_item_index(const PtKernelParams& p, unsigne
     return index < n;
 }
 
-// KIND: 0 sphere scene, 1 all-triangles loop, 2 LBVH, 3 culled loop. MATERIALS: false = the reference's shading (Phong
+// KIND: 0 sphere scene, 1 all-triangles loop, 2 LBVH, 3 culled loop, 4 / 7 direction grid, 5 per-lane walk in step. MATERIALS: false = the reference's shading (Phong
 // lobe, grey throughput, origin fixed at the camera), true = the diffuse/emissive mode (coloured throughput, emitted
 // radiance, origin moves to each hit point, so the ray-origin-specific triangle records cannot be used).
 template <int KIND, bool MATERIALS>
 __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKernelParams p) {
+    constexpr bool GRID = KIND == 4 || KIND == 7;   // direction grid: 4 = the wave runs its list loop, 7 = list remainders carried into the next trip
     __shared__ uint32_t s_stack[(KIND == 2 || KIND == 5) ? PT_TILE_WAVES : 1][(KIND == 2 || KIND == 5) ? PT_BVH_STACK : 1];
     __shared__ uint32_t s_lane_stack[KIND == 5 ? PT_TILE_WAVES : 1][KIND == 5 ? PT_LANE_STACK * 64 : 1];
     // Which tile and which of its samples this block renders. Blocks start in blockIdx order and the work list is sorted
@@ -926,7 +997,7 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
     unsigned shaded = 0;                      // per LANE: hits shaded
 
     // direction grid: whether queries look at the block bits first (they exist, and the view's queries mostly miss)
-    const bool use_occ = KIND == 4 && p.grid_occ != nullptr && *(const kuint32*)p.grid_occ_flag != 0u;
+    const bool use_occ = GRID && p.grid_occ != nullptr && *(const kuint32*)p.grid_occ_flag != 0u;
     CullRec cull0;
     if (KIND == 3) cull0 = load_cull(reinterpret_cast<const float4*>(p.cull), threadIdx.x & 63, p.num_triangles);
 
@@ -940,7 +1011,7 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
 #endif
         if (KIND == 3) {
             h = intersect_mesh_culled(p, d, want, cull0, tri_tests);
-        } else if (KIND == 4) {
+        } else if (GRID) {
             n = n_out;  // (kept when nothing is hit: no register to clear, and the caller reads the normal only after a hit)
             h = intersect_grid(p, d, want, lane_tests, n, use_occ);
         } else if (want) {
@@ -956,14 +1027,14 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
 #ifdef PT_V_COUNT_ITERS
         // measurement variant, direction grid: trips of the list loop as the WAVE ran them (the longest list among its lanes)
         // -> node_visits; wave queries in which more than one lane had something to test -> tri_tests
-        if (KIND == 4) {
+        if (GRID) {
             const unsigned mine = want ? lane_tests - tests_before : 0u;
             node_visits += __builtin_amdgcn_readfirstlane(__reduce_max_trips(mine));
             tri_tests += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(mine > 1u));
         }
 #endif
         const bool hit = want && h.id >= 0;
-        if (hit && KIND != 0 && !(KIND == 4 && p.normal_mode != 0)) n = mesh_normal(p, h);  // (the grid's records hold the geometric normal)
+        if (hit && KIND != 0 && !(GRID && p.normal_mode != 0)) n = mesh_normal(p, h);  // (the grid's records hold the geometric normal)
         n_out = n; t_out = h.t; id_out = h.id;
         return hit;
     };
@@ -1083,6 +1154,45 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
         rng.sx = 0.0f;
         pending = reuse; pend_hit = hit0; pend_n = N0; pend_t = t0; pend_id = id0;
     };
+    // Direction grid, second form of the loop (KIND 7; the host times both forms on a view's first long dispatches and keeps the
+    // quicker one): one triangle test per trip; a lane whose cell lists more carries the rest of the list (entry,
+    // position; best hit so far in pend_t / pend_id / pend_n; u, v, 1/det for an interpolated normal in LDS) into its next trip
+    // and shades one trip later -- instead of the wave running its list loop as often as its longest list, for a few lanes.
+    // Same tests, same lowest-index rule: the same image either way.
+    if (KIND == 7) {
+        __shared__ float s_uvo[PT_TILE_WAVES][3 * 64];
+        float* __restrict__ uvo = &s_uvo[threadIdx.x >> 6][threadIdx.x & 63];
+        uint32_t carry_entry = 0u, carry_pos = 0u;
+        bool listing = false;
+        while (remaining > 0) {
+            bool done = false;
+            if (!listing) {
+                if (p.depth <= 0) done = true;
+                else if (pending) done = shade_pending();
+            }
+            const bool want = !listing && !done;
+            bool more = listing;
+            if (want) {
+                more = grid_lookup(p, rd, true, use_occ, carry_entry, carry_pos);
+                pend_t = 1.0e38f; pend_id = -1;
+                ++traced;
+            }
+            if (__builtin_amdgcn_ballot_w64(want || listing)) ++trips;
+            if (more) more = grid_test_one(p, rd, carry_entry, carry_pos, pend_t, pend_id, pend_n, uvo, lane_tests);
+            if ((want || listing) && !more) {   // the query is answered
+                pend_hit = pend_id >= 0;
+                if (pend_hit && p.normal_mode == 0) {
+                    Hit h;
+                    h.t = pend_t; h.id = pend_id; h.u = uvo[0]; h.v = uvo[64]; h.ood = uvo[128];
+                    pend_n = mesh_normal(p, h);
+                }
+                pending = true;
+                done = !pend_hit;
+            }
+            listing = more;
+            if (done) end_sample();
+        }
+    } else
     while (KIND == 3 ? __builtin_amdgcn_ballot_w64(remaining > 0) != 0 : remaining > 0) {
         const bool live = remaining > 0;
         bool done = false;
@@ -1117,7 +1227,7 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
     unsigned rays = traced;
     if (reuse && in_window && sample_count > 0) rays += (unsigned)(sample_count - 1) + (first_from_cache ? 1u : 0u);
     const unsigned long long wave_rays = wave_sum(rays), wave_traced = wave_sum(traced);
-    const unsigned long long wave_tests = (KIND == 4 || KIND == 5) ? wave_sum(lane_tests) : 0ull;
+    const unsigned long long wave_tests = (GRID || KIND == 5) ? wave_sum(lane_tests) : 0ull;
     const unsigned long long wave_shaded = wave_sum(shaded);
     const unsigned wave_trips = __builtin_amdgcn_readfirstlane(__reduce_max_trips(trips));
     if ((threadIdx.x & 63) == 0 && wave_rays) {
@@ -1130,11 +1240,11 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
         if (p.tile_cost) {
             unsigned cost = wave_trips;
             if (KIND == 2) cost = 8u * wave_trips + __builtin_amdgcn_readfirstlane(node_visits) + __builtin_amdgcn_readfirstlane(tri_tests);
-            if (KIND == 4 || KIND == 5) cost = 8u * wave_trips + (unsigned)(wave_tests >> 4);
+            if (GRID || KIND == 5) cost = 8u * wave_trips + (unsigned)(wave_tests >> 4);
             atomicAdd(&p.tile_cost[tile], cost);
         }
 #ifdef PT_V_COUNT_ITERS
-        if (KIND == 4) {
+        if (GRID) {
             atomicAdd(&counters[2], (unsigned long long)__builtin_amdgcn_readfirstlane(node_visits));
             atomicAdd(&counters[3], (unsigned long long)__builtin_amdgcn_readfirstlane(tri_tests));
         }
@@ -1143,7 +1253,7 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
             atomicAdd(&counters[2], (unsigned long long)__builtin_amdgcn_readfirstlane(node_visits));
             atomicAdd(&counters[3], (unsigned long long)__builtin_amdgcn_readfirstlane(tri_tests));
         }
-        if (KIND == 4 || KIND == 5) atomicAdd(&counters[5], wave_tests);
+        if (GRID || KIND == 5) atomicAdd(&counters[5], wave_tests);
         if (wave_shaded) atomicAdd(&counters[6], wave_shaded);
         if (KIND == 1) {  // the loop visits every (live) record once per trip of the wave
             const unsigned n = MATERIALS ? (unsigned)p.num_triangles : (unsigned)live_triangles(p);
@@ -2406,6 +2516,7 @@ hipError_t pt_launch_render(const PtKernelParams& p, int program_kind, hipStream
         else if (p.bvh_nodes_abs) hipLaunchKernelGGL((pt_render_kernel<2, true>), grid, block, 0, stream, p);
         else hipLaunchKernelGGL((pt_render_kernel<1, true>), grid, block, 0, stream, p);
     }
+    else if (p.grid_cells && p.grid_carry) hipLaunchKernelGGL((pt_render_kernel<7, false>), grid, block, 0, stream, p);
     else if (p.grid_cells) hipLaunchKernelGGL((pt_render_kernel<4, false>), grid, block, 0, stream, p);
     else if (p.bvh_nodes) hipLaunchKernelGGL((pt_render_kernel<2, false>), grid, block, 0, stream, p);
     else if (p.cull) hipLaunchKernelGGL((pt_render_kernel<3, false>), grid, block, 0, stream, p);

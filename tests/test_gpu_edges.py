@@ -445,3 +445,59 @@ def test_work_list_dealt_to_the_xcds_changes_nothing(workload, size, shading, sp
             out[groups] = (t.readback().copy(), st["rays"], st["samples"])
     assert np.array_equal(out["0"][0].view(np.uint32), out["1"][0].view(np.uint32))
     assert out["0"][1:] == out["1"][1:]
+
+
+@pytest.mark.parametrize("workload,size,spp", [("cornell", (333, 201), 33), ("suzanne", (640, 360), 40), ("monkeyhead2", (480, 270), 24),
+                                               ("instanced", (960, 540), 16), ("torus", (400, 300), 20)])
+def test_both_forms_of_the_grid_kernels_loop_render_the_same(workload, size, spp):
+    """The direction-grid kernel exists twice: the wave runs its list loop as often as its longest list (PT_GRID_CARRY=0), or a lane
+    tests one triangle per trip and carries the rest of its cell's list into its next trip (=1). The library times both on a view
+    and keeps the quicker (unset). Same tests, same lowest-index rule: images, ray counts, camera-ray triangles and distances must
+    be identical bit for bit, over a cold dispatch, list rebuilds, split tiles, a window, a row partition and a camera move;
+    geometric and interpolated normals."""
+    import os
+    from pathtracer_amd import Tracer, capi
+    from pathtracer_amd.scenes import SceneData
+    scene = SceneData(workload, *size)
+    out = {}
+    for form in ("0", "1", None):
+        old = os.environ.get("PT_GRID_CARRY")
+        if form is None:
+            os.environ.pop("PT_GRID_CARRY", None)
+        else:
+            os.environ["PT_GRID_CARRY"] = form
+        try:
+            t = Tracer(0)
+        finally:
+            if old is None:
+                os.environ.pop("PT_GRID_CARRY", None)
+            else:
+                os.environ["PT_GRID_CARRY"] = old
+        with t:
+            scene.upload(t)
+            t.set_accel_mode(capi.ACCEL_GRID)
+            t.target_create(scene.width, scene.height)
+            forms = set()
+            for k in range(5):
+                t.dispatch(1 + k * spp, spp, 1)
+                forms.add(t.stats()["grid_lists_carried"])
+            ids, ts = t.readback_primary()
+            t.set_window(17, 9, scene.width - 40, scene.height - 30)
+            t.dispatch(1 + 5 * spp, spp, 1)
+            t.set_window(0, 0, 0, 0)
+            t.set_row_interleave(8, 1, 3)
+            t.dispatch(1 + 6 * spp, spp, 1)
+            t.set_row_interleave(16, 0, 1)
+            cam = np.array(scene.camera, np.float32).copy()
+            cam[0:3] += np.float32(0.01)        # the camera moves: new grid, the choice starts again
+            t.set_uniforms(cam, scene.num_triangles, 10)
+            t.dispatch(1 + 7 * spp, spp, 1)
+            t.dispatch(1 + 8 * spp, 1, 1)       # a single-sample frame
+            t.finish()
+            st = t.stats()
+            out[form] = (t.readback().copy(), ids.copy(), ts.copy(), st["rays"], st["rays_traced"], st["samples"], forms)
+    assert out["0"][6] == {0} and out["1"][6] == {1}
+    for form in ("1", None):
+        assert np.array_equal(out["0"][0].view(np.uint32), out[form][0].view(np.uint32)), form
+        assert np.array_equal(out["0"][1], out[form][1]) and np.array_equal(out["0"][2].view(np.uint32), out[form][2].view(np.uint32)), form
+        assert out["0"][3:6] == out[form][3:6], form
