@@ -2215,16 +2215,22 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_fold_samples_kernel(const 
 // launches (total, per-workgroup bucket counts, offsets, scatter); positions inside a workgroup's share of a bucket are
 // handed out atomically, so the list is always a complete cover whatever the order. The costs are only read (the caller
 // may run the scheduler again with another limit before clearing them).
-// tmp: [0..1] total cost (64 bit), [4 + 64 * block + bucket] that workgroup's count, then start, in the bucket.
+// tmp: [0..1] total cost (64 bit), [3] the most expensive tile's cost, [4 + 64 * block + bucket] that workgroup's count, then start, in the bucket.
 constexpr int PT_SCHED_BLOCKS = 64, PT_SCHED_THREADS = 256;
 
-__device__ __forceinline__ int sched_bucket(uint32_t c, int sort) {
-    if (!sort) return 0;
-    if (c < 2) return (int)c;
+// Bucket of an item of cost c (higher = more expensive = earlier in the list): the 64 buckets cover the eight octaves below the
+// most expensive tile's cost, eight to an octave; cheaper items share bucket 0. (Two buckets per octave over all 32 octaves, as
+// before, put most tiles of a view into one or two buckets whenever their costs cluster -- a wave whose pixels all end after one
+// query costs 8 x samples, whatever the samples --, and inside a bucket the order is raster order: the 1M triangles at 4K, 4,096
+// samples per dispatch, took 70 ms per dispatch with such a list and 57 ms with one that happened to cut the cluster in two.)
+__device__ __forceinline__ int sched_bucket(uint32_t c, int sort, uint32_t cmax) {
+    if (!sort || c == 0u) return 0;
+    const int octave = __builtin_clz(c) - __builtin_clz(cmax | 1u);   // octaves below the top one (never negative: c <= cmax)
+    if (octave < 0) return 63;
+    if (octave >= 8) return 0;
     const int lg = 31 - __builtin_clz(c);
-    const int half = (int)((c >> (lg - 1)) & 1u);
-    const int b = 2 * lg + half;
-    return b > 63 ? 63 : b;
+    const int sub = (int)((lg >= 3 ? c >> (lg - 3) : c << (3 - lg)) & 7u);
+    return 63 - (octave * 8 + (7 - sub));
 }
 // pieces of a tile and samples per piece
 __device__ __forceinline__ int sched_split(uint32_t c, unsigned long long granule, int num_samples, int& per_piece) {
@@ -2253,7 +2259,7 @@ __device__ __forceinline__ void sched_share(int n, int& begin, int& end) {
 // tiles are cut, in raster order, into `groups` runs of equal cost (image bands), group g's items stand at the list positions
 // g, g + groups, g + 2 groups, ... (most expensive first within the group), and the XCD that takes those blocks keeps reading
 // the same part of the scene. Groups differ in length; the unused positions of the shorter ones hold PT_NO_TILE.
-// tmp: [0..1] total cost (64 bit), [2] items of the longest group, [4 + g] items of group g, [16 + 2 w] cost of workgroup w's
+// tmp: [0..1] total cost (64 bit), [2] items of the longest group, [3] the most expensive tile's cost, [4 + g] items of group g, [16 + 2 w] cost of workgroup w's
 // share of the tiles (64 bit), [PT_SCHED_COUNTS + ((w * 8 + g) * 64 + bucket)] that workgroup's count, then start, in the bucket.
 constexpr int PT_SCHED_SHARES = 16, PT_SCHED_COUNTS = PT_SCHED_SHARES + 2 * PT_SCHED_BLOCKS, PT_SCHED_MAX_GROUPS = 8;
 static_assert(PT_SCHED_COUNTS + PT_SCHED_BLOCKS * PT_SCHED_MAX_GROUPS * 64 == PT_SCHED_TMP_WORDS, "scratch of the scheduler");
@@ -2311,7 +2317,9 @@ __global__ __launch_bounds__(PT_SCHED_THREADS) void pt_sched_total_kernel(const 
     int begin, end;
     sched_share(n, begin, end);
     unsigned long long mine = 0;
-    for (int i = begin + (int)threadIdx.x; i < end; i += PT_SCHED_THREADS) mine += cost[i];
+    uint32_t highest = 0;
+    for (int i = begin + (int)threadIdx.x; i < end; i += PT_SCHED_THREADS) { mine += cost[i]; highest = max(highest, cost[i]); }
+    if (highest) atomicMax(&tmp[3], highest);   // the most expensive tile's cost (the buckets are laid out below it)
     mine = wave_sum(mine);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mine;
     __syncthreads();
@@ -2329,10 +2337,11 @@ __global__ __launch_bounds__(PT_SCHED_THREADS) void pt_sched_count_kernel(const 
     for (int k = threadIdx.x; k < PT_SCHED_MAX_GROUPS * 64; k += PT_SCHED_THREADS) hist[k >> 6][k & 63] = 0;
     __syncthreads();
     const unsigned long long granule = sched_granule(tmp, max_split);
+    const uint32_t cmax = tmp[3];
     sched_for_tiles(cost, n, groups, tmp, [&](int, uint32_t c, int group) {
         int per_piece;
         const int k = sched_split(c, granule, num_samples, per_piece);
-        atomicAdd(&hist[group][sched_bucket(c / (uint32_t)k, sort)], (uint32_t)k);
+        atomicAdd(&hist[group][sched_bucket(c / (uint32_t)k, sort, cmax)], (uint32_t)k);
     });
     __syncthreads();
     for (int k = threadIdx.x; k < groups * 64; k += PT_SCHED_THREADS) tmp[sched_counter(blockIdx.x, k >> 6, k & 63)] = hist[k >> 6][k & 63];
@@ -2392,10 +2401,11 @@ __global__ __launch_bounds__(PT_SCHED_THREADS) void pt_sched_scatter_kernel(cons
             }
     }
     const unsigned long long granule = sched_granule(tmp, max_split);
+    const uint32_t cmax = tmp[3];
     sched_for_tiles(cost, n, groups, tmp, [&](int i, uint32_t c, int group) {
         int per_piece;
         const int k = sched_split(c, granule, num_samples, per_piece);
-        const uint32_t first = atomicAdd(&cursor[group][sched_bucket(c / (uint32_t)k, sort)], (uint32_t)k);
+        const uint32_t first = atomicAdd(&cursor[group][sched_bucket(c / (uint32_t)k, sort, cmax)], (uint32_t)k);
         int slot = -1;
         if (k > 1) {
             slot = (int)atomicAdd(&counts[1], 1u);
