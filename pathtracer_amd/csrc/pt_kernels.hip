@@ -2223,14 +2223,18 @@ constexpr int PT_SCHED_BLOCKS = 64, PT_SCHED_THREADS = 256;
 // before, put most tiles of a view into one or two buckets whenever their costs cluster -- a wave whose pixels all end after one
 // query costs 8 x samples, whatever the samples --, and inside a bucket the order is raster order: the 1M triangles at 4K, 4,096
 // samples per dispatch, took 70 ms per dispatch with such a list and 57 ms with one that happened to cut the cluster in two.)
+#ifndef PT_SCHED_SUB_LOG
+#define PT_SCHED_SUB_LOG 3
+#endif
+#define PT_SCHED_SUB (1 << PT_SCHED_SUB_LOG)   // buckets per octave
 __device__ __forceinline__ int sched_bucket(uint32_t c, int sort, uint32_t cmax) {
     if (!sort || c == 0u) return 0;
     const int octave = __builtin_clz(c) - __builtin_clz(cmax | 1u);   // octaves below the top one (never negative: c <= cmax)
     if (octave < 0) return 63;
-    if (octave >= 8) return 0;
+    if (octave >= 64 / PT_SCHED_SUB) return 0;
     const int lg = 31 - __builtin_clz(c);
-    const int sub = (int)((lg >= 3 ? c >> (lg - 3) : c << (3 - lg)) & 7u);
-    return 63 - (octave * 8 + (7 - sub));
+    const int sub = (int)((lg >= PT_SCHED_SUB_LOG ? c >> (lg - PT_SCHED_SUB_LOG) : c << (PT_SCHED_SUB_LOG - lg)) & (uint32_t)(PT_SCHED_SUB - 1));
+    return 63 - (octave * PT_SCHED_SUB + (PT_SCHED_SUB - 1 - sub));
 }
 // pieces of a tile and samples per piece
 __device__ __forceinline__ int sched_split(uint32_t c, unsigned long long granule, int num_samples, int& per_piece) {
