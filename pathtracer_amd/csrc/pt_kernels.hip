@@ -1165,6 +1165,9 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
         uint32_t carry_entry = 0u, carry_pos = 0u;
         bool listing = false;
         while (remaining > 0) {
+#ifdef PT_V_LIVE_COUNT
+            node_visits += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true));  // measurement build: lanes still in the loop, per trip
+#endif
             bool done = false;
             if (!listing) {
                 if (p.depth <= 0) done = true;
@@ -1195,6 +1198,9 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
     } else
     while (KIND == 3 ? __builtin_amdgcn_ballot_w64(remaining > 0) != 0 : remaining > 0) {
         const bool live = remaining > 0;
+#ifdef PT_V_LIVE_COUNT
+        if (GRID) node_visits += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true));
+#endif
         bool done = false;
         if (live && p.depth <= 0) {
             done = true;
@@ -1243,6 +1249,9 @@ __global__ __launch_bounds__(PT_TILE_THREADS) void pt_render_kernel(const PtKern
             if (GRID || KIND == 5) cost = 8u * wave_trips + (unsigned)(wave_tests >> 4);
             atomicAdd(&p.tile_cost[tile], cost);
         }
+#ifdef PT_V_LIVE_COUNT
+        if (GRID) atomicAdd(&counters[2], (unsigned long long)__builtin_amdgcn_readfirstlane(node_visits));
+#endif
 #ifdef PT_V_COUNT_ITERS
         if (GRID) {
             atomicAdd(&counters[2], (unsigned long long)__builtin_amdgcn_readfirstlane(node_visits));

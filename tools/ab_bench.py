@@ -33,6 +33,7 @@ VARIANTS = {
     "batch12": ["-DPT_SHADE_BATCH=12"], "batch24": ["-DPT_SHADE_BATCH=24"],
     "reshade": ["-DPT_V_RESHADE"],   # materials loop: a lane whose sample ended in Shade() shades its next sample's camera hit in the same trip
     "sub4": ["-DPT_SCHED_SUB_LOG=2"], "sub16": ["-DPT_SCHED_SUB_LOG=4"],   # work list: 4 / 16 cost buckets to an octave (16 / 4 octaves) instead of 8
+    "live": ["-DPT_V_LIVE_COUNT"],   # direction grid: lanes still in the loop summed over the wave trips -> bvh_node_fetches (lane_slots minus that = slots of lanes whose pixel is finished)
     "iters": ["-DPT_V_COUNT_ITERS"],   # direction grid: list-loop trips per wave in bvh_node_fetches, lanes with >1 test in bvh_triangle_fetches
 }
 
