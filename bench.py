@@ -157,6 +157,8 @@ def roofline(st, kernel_ms, scene, shading, pmc, pmc_note):
     lane_util = per["rays_traced"] / per["lane_slots"] if per["lane_slots"] else 0.0
     out = {"kernel": kernel, "kernel_ms": kernel_ms, "lane_utilisation": lane_util,
            "events_per_launch": {k: v for k, v in per.items() if v}}
+    if st.get("gathered_pixels"):   # a sparse view: the waves' tiles are 64 gathered hit pixels each, the sky pixels have a pass of their own
+        out["gathered_pixels"] = st["gathered_pixels"]
     brute = per["rays_traced"] * FLOP_PER_TRI_TEST_SHADER * scene.num_triangles
     if kind in ("wave_walk", "lane_walk"):
         # dependent record fetches. Per-wave walk: 64-byte node and triangle records, one scalar fetch serves the wave; per-lane

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 6
+#define PT_ABI_VERSION 7
 
 typedef enum PtStatus {
     PT_OK = 0,
@@ -147,6 +147,10 @@ typedef struct PtStats {
                                   wave runs its list loop as often as its longest list; 1: a lane tests one triangle per trip and
                                   carries the rest of its cell's list into the next. Same image; the library times both on a
                                   view's first long dispatches and keeps the quicker (the field was reserved before ABI 6) */
+    uint32_t gathered_pixels;  /* sparse views (since ABI 7): when the last pt_dispatch rendered the pixels whose camera ray hits the
+                                  mesh gathered into tiles of 64 instead of the window's 8x8 blocks (the other pixels are folded by a
+                                  pass of their own; same image), how many such pixels the view has; 0 = it rendered the blocks */
+    uint32_t gathered_tiles;   /* ... and how many tiles they make */
 } PtStats;
 
 typedef struct PtContext PtContext; /* opaque */

@@ -32,7 +32,8 @@ class PtStats(C.Structure):
                 ("bvh_triangle_fetches", C.c_uint64), ("grid_triangle_tests", C.c_uint64), ("grid_entries", C.c_uint64),
                 ("shaded_hits", C.c_uint64), ("loop_triangle_visits", C.c_uint64), ("loop_full_tests", C.c_uint64), ("lane_walk_records", C.c_uint64),
                 ("dispatches", C.c_uint32),
-                ("last_dispatch_ms", C.c_float), ("total_dispatch_ms", C.c_double), ("bvh_sweeps", C.c_uint32), ("grid_lists_carried", C.c_uint32)]
+                ("last_dispatch_ms", C.c_float), ("total_dispatch_ms", C.c_double), ("bvh_sweeps", C.c_uint32), ("grid_lists_carried", C.c_uint32),
+                ("gathered_pixels", C.c_uint32), ("gathered_tiles", C.c_uint32)]
 
 
 class PtError(RuntimeError):
@@ -277,7 +278,7 @@ class Tracer:
         return {"rays": s.rays, "rays_traced": s.rays_traced, "samples": s.samples, "lane_slots": s.lane_slots, "bvh_node_fetches": s.bvh_node_fetches,
                 "bvh_triangle_fetches": s.bvh_triangle_fetches, "grid_triangle_tests": s.grid_triangle_tests,
                 "grid_entries": s.grid_entries, "shaded_hits": s.shaded_hits, "loop_triangle_visits": s.loop_triangle_visits,
-                "loop_full_tests": s.loop_full_tests, "lane_walk_records": s.lane_walk_records, "dispatches": s.dispatches, "bvh_sweeps": s.bvh_sweeps, "grid_lists_carried": s.grid_lists_carried,
+                "loop_full_tests": s.loop_full_tests, "lane_walk_records": s.lane_walk_records, "dispatches": s.dispatches, "bvh_sweeps": s.bvh_sweeps, "grid_lists_carried": s.grid_lists_carried, "gathered_pixels": s.gathered_pixels, "gathered_tiles": s.gathered_tiles,
                 "last_dispatch_ms": s.last_dispatch_ms, "total_dispatch_ms": s.total_dispatch_ms}
 
     def reset_stats(self):

@@ -211,6 +211,29 @@ struct PtContext {
         int32_t num_triangles, win[4], rows[3], normal_mode, accel_mode;
         uint32_t program;
     } primary_cache_key{};
+    // Sparse views: the pixels whose camera ray hits the mesh, gathered block after block into tiles of 64 (PtKernelParams::pixel_list),
+    // so that the sky pixels of blocks on a silhouette do not occupy lanes; the other pixels are folded by pt_sky_fold_kernel.
+    // Built per view (camera, window, row partition, mesh) from one query of the direction grid per pixel.
+    uint32_t* d_pixel_list = nullptr;              // one word per target pixel, rounded up to 64
+    unsigned long long* d_pixel_mask = nullptr;    // per 8x8 block of the window: which of its pixels are in the list
+    uint32_t* d_pixel_counts = nullptr;            // per block (scratch of the build), then d_pixel_offsets; one word for the total
+    uint32_t* d_pixel_offsets = nullptr;
+    uint32_t* d_pixel_total = nullptr;
+    int pixel_list_mode = -1;       // PT_PIXEL_LIST=0: never; =1: whenever a view has a direction grid; default: from a view's second
+                                    // dispatch on, for dispatches of kPixelListMinSamples samples or more, when at most 3/4 of its pixels see the mesh
+    bool pixel_list_valid = false;
+    int32_t pixel_tiles = 0;
+    uint32_t pixel_hits = 0;
+    uint32_t pixel_list_id = 0;     // counts the builds (never 0 once built): what the tile costs and the work list refer to
+    struct PixelListKey {
+        float camera[12];
+        int32_t win[4], rows[3], size[2], num_triangles;
+        uint32_t grid_id;
+    } pixel_list_key{};
+    uint32_t grid_id = 0;           // counts the builds of the direction grid
+    bool use_pixel_list = false;    // what pt_dispatch decided for its launches
+    bool last_gathered = false;     // ... and what the last dispatch did (PtStats::gathered_pixels)
+    uint32_t sched_numbering = 0;   // 0: the tile costs refer to the window's 8x8 blocks; otherwise to the tiles of that pixel list
     int xcd_groups = 0;             // PT_XCD_GROUPS=1: the work list of multi-sample dispatches is dealt to the XCDs in image bands of
                                     // equal cost (an experiment that is kept: see kXcdGroups)
     int list_groups = 1;            // what the list in use was built with
@@ -303,6 +326,14 @@ void free_target(PtContext* ctx) {
     if (ctx->d_primary_cache) (void)hipFree(ctx->d_primary_cache);
     ctx->d_primary_cache = nullptr;
     ctx->primary_cache_valid = false;
+    void* pixel_arrays[] = {ctx->d_pixel_list, ctx->d_pixel_mask, ctx->d_pixel_counts, ctx->d_pixel_offsets, ctx->d_pixel_total};
+    for (void* q : pixel_arrays)
+        if (q) (void)hipFree(q);
+    ctx->d_pixel_list = ctx->d_pixel_counts = ctx->d_pixel_offsets = ctx->d_pixel_total = nullptr;
+    ctx->d_pixel_mask = nullptr;
+    ctx->pixel_list_valid = false;
+    ctx->use_pixel_list = false;
+    ctx->sched_numbering = 0;
     if (ctx->d_sample_scratch) (void)hipFree(ctx->d_sample_scratch);
     ctx->d_items = nullptr;
     ctx->d_sched_counts = ctx->d_split_tiles = nullptr;
@@ -456,6 +487,7 @@ PtStatus build_grid(PtContext* ctx) {
         // (a new grid: which form of the render loop suits the view is found out again)
         ctx->grid_carry = ctx->grid_carry_override > 0;
         ctx->carry_trial = ctx->grid_carry_override >= 0 ? 4 : 0;
+        ++ctx->grid_id;   // (and which pixels see the mesh)
     }
     ctx->grid_entries = entries;
     ctx->grid_built = true;
@@ -798,6 +830,7 @@ PtStatus pt_create(int32_t device, PtContext** out_ctx) {
     if (const char* g = getenv("PT_PRIMARY_CACHE")) ctx->primary_cache_enabled = g[0] != '0';
     if (const char* g = getenv("PT_GRID_OCC")) ctx->grid_occ_override = atoi(g) != 0;
     if (const char* g = getenv("PT_GRID_CARRY")) ctx->grid_carry_override = atoi(g) != 0;
+    if (const char* g = getenv("PT_PIXEL_LIST")) ctx->pixel_list_mode = atoi(g) != 0;
     if (const char* g = getenv("PT_GRID_QUEUE")) ctx->grid_queue_override = atoi(g);
     if (const char* g = getenv("PT_GRID_FINE_AFTER")) ctx->grid_fine_after = atof(g);
     if (const char* g = getenv("PT_FAIL_GRID_ALLOC")) ctx->fail_grid_alloc = atoi(g);
@@ -1109,6 +1142,14 @@ static PtStatus target_common(PtContext* ctx, int32_t width, int32_t height) {
     PT_HIP_TRY(hipMalloc(&ctx->d_split_tiles, (size_t)PT_MAX_SPLIT_FACTOR * ctx->wave_slots * sizeof(uint32_t)));
     PT_HIP_TRY(hipMalloc(&ctx->d_primary_cache, n * sizeof(float4)));
     ctx->primary_cache_valid = false;
+    if (PT_TILE_WAVES == 1 && width <= 65535 && height <= 65535) {   // (a list entry is y << 16 | x)
+        PT_HIP_TRY(hipMalloc(&ctx->d_pixel_list, (n + 63) / 64 * 64 * sizeof(uint32_t)));
+        PT_HIP_TRY(hipMalloc(&ctx->d_pixel_mask, tiles * sizeof(unsigned long long)));
+        PT_HIP_TRY(hipMalloc(&ctx->d_pixel_counts, tiles * sizeof(uint32_t)));
+        PT_HIP_TRY(hipMalloc(&ctx->d_pixel_offsets, tiles * sizeof(uint32_t)));
+        PT_HIP_TRY(hipMalloc(&ctx->d_pixel_total, sizeof(uint32_t)));
+    }
+    ctx->pixel_list_valid = false;
     ctx->sched_have_cost = false;
     return PT_OK;
 }
@@ -1214,6 +1255,43 @@ PtStatus pt_set_uniforms(PtContext* ctx, const PtUniforms* uniforms) {
 
 }  // extern "C"
 namespace {
+// Whether the launches of this pt_dispatch render the gathered hit pixels of a sparse view (ctx->use_pixel_list), building the
+// list when the view has none yet. `p` as fill_params left it.
+constexpr int kPixelListMinSamples = 8;   // shorter dispatches (frame loops) keep the window's blocks: the sky pass would cost them more than the idle lanes
+PtStatus choose_pixel_list(PtContext* ctx, const PtKernelParams& p, const Program* prog, int32_t num_samples) {
+    ctx->use_pixel_list = false;
+    if (PT_TILE_WAVES != 1 || ctx->pixel_list_mode == 0 || prog->kind != PT_PROGRAM_MESH || p.grid_cells == nullptr || !ctx->primary_reuse || p.depth <= 0 ||
+        ctx->sched_mode == 0 || ctx->d_pixel_list == nullptr || ctx->no_alloc)
+        return PT_OK;
+    if (ctx->pixel_list_mode != 1 && num_samples < kPixelListMinSamples) return PT_OK;
+    PtContext::PixelListKey key;
+    memset(&key, 0, sizeof key);
+    memcpy(key.camera, p.ro, 12); memcpy(key.camera + 3, p.llc, 12); memcpy(key.camera + 6, p.hor, 12); memcpy(key.camera + 9, p.ver, 12);
+    memcpy(key.win, ctx->win, sizeof key.win);
+    key.rows[0] = p.row_block; key.rows[1] = p.row_index; key.rows[2] = p.row_count;
+    key.size[0] = ctx->width; key.size[1] = ctx->height;
+    key.num_triangles = p.num_triangles;
+    key.grid_id = ctx->grid_id;
+    if (!ctx->pixel_list_valid || memcmp(&key, &ctx->pixel_list_key, sizeof key) != 0) {
+        if (ctx->pixel_list_mode != 1 && ctx->dispatches_here < 1) return PT_OK;   // a view that stays: from its second dispatch on
+        ctx->pixel_list_valid = false;
+        PT_HIP_TRY(pt_launch_pixel_list(p, ctx->d_pixel_mask, ctx->d_pixel_counts, ctx->d_pixel_offsets, ctx->d_pixel_list, ctx->d_pixel_total, ctx->stream));
+        uint32_t total = 0;
+        PT_HIP_TRY(hipMemcpyAsync(&total, ctx->d_pixel_total, sizeof total, hipMemcpyDeviceToHost, ctx->stream));
+        PT_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ctx->pixel_hits = total;
+        ctx->pixel_tiles = (int32_t)((total + 63u) / 64u);
+        ctx->pixel_list_key = key;
+        ctx->pixel_list_valid = true;
+        if (++ctx->pixel_list_id == 0) ctx->pixel_list_id = 1;
+        if (getenv("PT_DEBUG_SCHED"))
+            fprintf(stderr, "[pt pixels] %u of the window's %lld pixels see the mesh: %d tiles of 64\n", total, (long long)ctx->win[2] * ctx->win[3], ctx->pixel_tiles);
+    }
+    const unsigned long long owned = (unsigned long long)ctx->win[2] * (unsigned long long)ctx->win[3] / (unsigned long long)(ctx->row_count > 1 ? ctx->row_count : 1);
+    ctx->use_pixel_list = ctx->pixel_tiles > 0 && (ctx->pixel_list_mode == 1 || 4ull * ctx->pixel_hits <= 3ull * owned);
+    return PT_OK;
+}
+
 // First half of a render launch over a range of samples: kernel parameters, source and destination image.
 PtStatus begin_pass(PtContext* ctx, PtKernelParams* pp, const Program** prog_out, int32_t first_sample, int32_t num_samples, int32_t stride) {
     PtKernelParams& p = *pp;
@@ -1244,9 +1322,14 @@ PtStatus dispatch_range(PtContext* ctx, int32_t first_sample, int32_t num_sample
     // Tile order: the costs measured by the previous dispatch of this same window put the expensive tiles first.
     // It is only a scheduling hint (any order renders the same image), so stale costs after a camera or scene change
     // are harmless.
+    if (ctx->use_pixel_list) {   // (decided by pt_dispatch for all its launches)
+        p.pixel_list = ctx->d_pixel_list;
+        p.pixel_tiles = ctx->pixel_tiles;
+    }
     if (ctx->sched_mode != 0 && prog->kind != PT_PROGRAM_CPU_TRACER) {
-        const int tiles = PT_TILES_ACROSS(ctx->win[2]) * PT_TILES_ACROSS(ctx->win[3]);
-        const bool same_window = memcmp(ctx->sched_win, ctx->win, sizeof ctx->win) == 0;
+        const int tiles = p.pixel_list ? p.pixel_tiles : PT_TILES_ACROSS(ctx->win[2]) * PT_TILES_ACROSS(ctx->win[3]);
+        const uint32_t numbering = p.pixel_list ? ctx->pixel_list_id : 0u;
+        const bool same_window = memcmp(ctx->sched_win, ctx->win, sizeof ctx->win) == 0 && ctx->sched_numbering == numbering;
         if (ctx->sched_have_cost && same_window) {
             // The list stays valid for any later dispatch of the same window and sample count (it only has to cover
             // every tile and sample once), so a frame loop does not pay for the scheduler on every frame. It is rebuilt
@@ -1351,6 +1434,7 @@ PtStatus dispatch_range(PtContext* ctx, int32_t first_sample, int32_t num_sample
         p.tile_cost = ctx->d_tile_cost;
         ctx->cost_samples += num_samples;
         memcpy(ctx->sched_win, ctx->win, sizeof ctx->win);
+        ctx->sched_numbering = numbering;
         ctx->sched_have_cost = true;
     }
     return end_pass(ctx, p, prog, num_samples);
@@ -1407,6 +1491,13 @@ PtStatus end_pass(PtContext* ctx, PtKernelParams& p, const Program* prog, int32_
     if (timed) PT_HIP_TRY(hipEventRecord(ctx->ev_trial[0], ctx->stream));
     PT_HIP_TRY(pt_launch_render(p, (int)prog->kind, ctx->stream));
     if (timed) PT_HIP_TRY(hipEventRecord(ctx->ev_trial[1], ctx->stream));
+    ctx->last_gathered = p.pixel_list != nullptr;
+    if (p.pixel_list) {   // the window's other pixels: every sample is the sky colour of their camera ray
+        PtKernelParams q = p;
+        q.pixel_list = nullptr;
+        q.pixel_tiles = 0;
+        PT_HIP_TRY(pt_launch_sky_fold(q, ctx->d_pixel_mask, ctx->stream));
+    }
     ctx->current ^= 1;  // PathTracer.cpp:1493
     uint64_t rows = (uint64_t)ctx->win[3];
     if (ctx->row_count > 1) {  // rows of the window that belong to this renderer
@@ -1448,6 +1539,8 @@ PtStatus pt_dispatch(PtContext* ctx, int32_t first_sample, int32_t num_samples, 
         s = fill_params(ctx, &p, &prog);
         ctx->grid_fine_over_move = false;
         if (s != PT_OK) return s;
+        s = choose_pixel_list(ctx, p, prog, num_samples);
+        if (s != PT_OK) return s;
     }
     if (ctx->timing) {
         s = collect_timing(ctx);
@@ -1458,7 +1551,8 @@ PtStatus pt_dispatch(PtContext* ctx, int32_t first_sample, int32_t num_samples, 
     // in raster order with whole tiles as the unit: measured 12.1 instead of 8.0 ms for 256 samples of the 1080p Cornell
     // box, and far worse where few tiles carry the work. Its first samples are therefore rendered on their own; the costs
     // they record schedule the rest. Samples are folded in the same order either way, so the image does not change.
-    const bool same_window = memcmp(ctx->sched_win, ctx->win, sizeof ctx->win) == 0;
+    const bool same_window = memcmp(ctx->sched_win, ctx->win, sizeof ctx->win) == 0 &&
+                             ctx->sched_numbering == (ctx->use_pixel_list ? ctx->pixel_list_id : 0u);
     const Program* current = find_program(ctx, ctx->current_program);
     const bool blind = ctx->sched_mode == 2 && (!ctx->sched_have_cost || !same_window || ctx->costs_stale) &&
                        !(current && current->kind == PT_PROGRAM_CPU_TRACER);
@@ -1715,6 +1809,8 @@ PtStatus pt_get_stats(PtContext* ctx, PtStats* out) {
     out->dispatches = ctx->dispatches;
     out->bvh_sweeps = ctx->bvh_built ? (uint32_t)ctx->bvh_refit_passes : 0u;
     out->grid_lists_carried = ctx->last_grid_carry ? 1u : 0u;
+    out->gathered_pixels = ctx->last_gathered ? ctx->pixel_hits : 0u;
+    out->gathered_tiles = ctx->last_gathered ? (uint32_t)ctx->pixel_tiles : 0u;
     out->last_dispatch_ms = ctx->last_ms;
     out->total_dispatch_ms = ctx->total_ms;
     return PT_OK;

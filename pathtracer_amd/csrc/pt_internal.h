@@ -209,6 +209,9 @@ struct PtKernelParams {
                                         // samples of split tiles, folded afterwards
     int32_t max_items, max_split_tiles; // launch sizes (upper bounds of the two counts)
     uint32_t* tile_cost;                // per tile: loop trips spent on it in this dispatch (scheduling hint), or null
+    const uint32_t* pixel_list;         // sparse views: tile t, lane l render the pixel pixel_list[64 t + l] = y << 16 | x (PT_NO_PIXEL: none) instead of
+                                        // the 8x8 block t of the window: the pixels whose camera ray hits the mesh, gathered in block order
+    int32_t pixel_tiles;                // ... and how many such tiles there are
     float4* primary_cache;              // optional, one per pixel of the target: the camera ray's hit (normal.xyz, triangle index bits; < 0 = miss)
     int32_t primary_cache_valid;        // 1: read it; 0: evaluate the camera ray and write it
     int32_t* out_ids;                   // primary pass only
@@ -251,6 +254,16 @@ hipError_t pt_launch_schedule_items(const uint32_t* tile_cost, PtWorkItem* items
 // *flag <- whether the direction grid's queries should consult the block bits, from the statistics counters (see the kernel)
 hipError_t pt_launch_grid_occ_flag(const unsigned long long* counters, unsigned long long samples, uint32_t* flag, hipStream_t stream);
 hipError_t pt_launch_primary(const PtKernelParams& p, int program_kind, hipStream_t stream);
+// Sparse views (see PtKernelParams::pixel_list). `p` describes the view and its direction grid (pixel_list null).
+// pt_launch_pixel_list: mask[b] <- which pixels of the window's 8x8 block b have a camera ray that hits the mesh (bit l = lane l),
+// list <- those pixels block after block, padded with PT_NO_PIXEL to a multiple of 64 (`list` holds one word per window pixel,
+// rounded up to 64), *total <- how many. counts / offsets: one word per block each (scratch).
+// pt_launch_sky_fold: what the render kernels do for the window's OTHER pixels (every sample is the sky colour of the camera
+// ray): folds p.num_samples samples from p.src into p.dst, counts their rays, fills their primary-cache entries when asked.
+#define PT_NO_PIXEL 0xffffffffu
+hipError_t pt_launch_pixel_list(const PtKernelParams& p, unsigned long long* mask, uint32_t* counts, uint32_t* offsets, uint32_t* list, uint32_t* total,
+                                hipStream_t stream);
+hipError_t pt_launch_sky_fold(const PtKernelParams& p, const unsigned long long* mask, hipStream_t stream);
 // every camera ray (and p.verify_bounces generations of bounce rays) through the structure `p` selects AND through the loop
 // over all of p.verify_tris; counts into p.verify_out. hipErrorInvalidValue when `p` selects no structure to check.
 hipError_t pt_launch_verify(const PtKernelParams& p, hipStream_t stream);

@@ -894,8 +894,14 @@ __device__ __forceinline__ void shade_materials(Rng& rng, const float* __restric
 }
 
 __device__ __forceinline__ bool pixel_of_lane(const PtKernelParams& p, int tile, int& x, int& y) {
-    // a wave covers an 8x8 pixel block; the workgroup's PT_TILE_WAVES waves tile a PT_TILE_DIM square
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (PT_TILE_WAVES == 1 && p.pixel_list) {  // sparse view: the tile is 64 entries of the list of pixels that see the mesh
+        const uint32_t e = p.pixel_list[(size_t)tile * 64 + lane];
+        x = (int)(e & 0xffffu);
+        y = (int)(e >> 16);
+        return e != PT_NO_PIXEL;
+    }
+    // a wave covers an 8x8 pixel block; the workgroup's PT_TILE_WAVES waves tile a PT_TILE_DIM square
     const int tiles_x = PT_TILES_ACROSS(p.win_w);
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int lx = tx * PT_TILE_DIM + (wave & 1) * 8 + (lane & 7);
@@ -2435,7 +2441,98 @@ __global__ __launch_bounds__(PT_SCHED_THREADS) void pt_sched_scatter_kernel(cons
     });
 }
 
-int window_tiles(const PtKernelParams& p) { return PT_TILES_ACROSS(p.win_w) * PT_TILES_ACROSS(p.win_h); }
+// ---- sparse views: the pixels that see the mesh, gathered -------------------------------------------------------------------
+// In a view of small objects most 8x8 blocks that contain a hit pixel also contain sky pixels, whose lanes have nothing to do
+// while the wave works (1M triangles at 4K: a third of the lane slots). All camera rays start at the camera, so whether a
+// pixel sees the mesh is one query of the direction grid per pixel and camera position: the hit pixels are listed block after
+// block (neighbours stay neighbours), 64 consecutive entries are a wave's tile, and the other pixels -- every sample the sky
+// colour of the camera ray -- are folded by pt_sky_fold_kernel with the render kernels' own operations.
+__global__ __launch_bounds__(64) void pt_pixel_mask_kernel(const PtKernelParams p, unsigned long long* __restrict__ mask, uint32_t* __restrict__ counts) {
+    int x, y;
+    const bool mine = pixel_of_lane(p, (int)blockIdx.x, x, y);
+    bool hit = false;
+    if (mine) {
+        unsigned tests = 0;
+        v3 n = V(0.f, 0.f, 0.f);
+        hit = intersect_grid(p, primary_direction(p, (float)x + 0.5f, (float)y + 0.5f), true, tests, n, p.grid_occ != nullptr).id >= 0;
+    }
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+    if (threadIdx.x == 0) {
+        mask[blockIdx.x] = m;
+        counts[blockIdx.x] = (uint32_t)__builtin_popcountll(m);
+    }
+}
+
+// offsets <- exclusive prefix sums of counts[0..n), *total <- their sum (one workgroup: a few hundred thousand blocks at most)
+__global__ __launch_bounds__(1024) void pt_pixel_offsets_kernel(const uint32_t* __restrict__ counts, int n, uint32_t* __restrict__ offsets, uint32_t* __restrict__ total) {
+    __shared__ uint32_t part[1024];
+    const int per = (n + 1023) / 1024;
+    const int begin = (int)threadIdx.x * per, end = begin + per < n ? begin + per : n;
+    uint32_t sum = 0;
+    for (int i = begin; i < end; ++i) sum += counts[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const uint32_t v = threadIdx.x >= (unsigned)off ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;
+    for (int i = begin; i < end; ++i) {
+        offsets[i] = run;
+        run += counts[i];
+    }
+    if (threadIdx.x == 1023) *total = part[1023];
+}
+
+__global__ __launch_bounds__(64) void pt_pixel_scatter_kernel(const PtKernelParams p, const unsigned long long* __restrict__ mask,
+                                                              const uint32_t* __restrict__ offsets, uint32_t* __restrict__ list) {
+    int x, y;
+    (void)pixel_of_lane(p, (int)blockIdx.x, x, y);
+    const unsigned long long m = mask[blockIdx.x];
+    const unsigned lane = threadIdx.x;
+    if ((m >> lane) & 1ull) list[offsets[blockIdx.x] + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = ((uint32_t)y << 16) | (uint32_t)x;
+}
+
+__global__ __launch_bounds__(64) void pt_sky_fold_kernel(const PtKernelParams p, const unsigned long long* __restrict__ mask) {
+    const unsigned long long m = mask[blockIdx.x];
+    if (m == ~0ull) return;
+    int x, y;
+    const bool mine = pixel_of_lane(p, (int)blockIdx.x, x, y) && !((m >> threadIdx.x) & 1ull);
+    if (mine) {
+        const size_t pix = (size_t)y * p.width + x;
+        const v3 rd0 = primary_direction(p, (float)x + 0.5f, (float)y + 0.5f);
+        const float4 prev = reinterpret_cast<const float4*>(p.src)[pix];
+        float mr = prev.x, mg = prev.y, mb = prev.z;
+        // fs:408-410 with energy 1, folded as the render kernels fold it (pt_render_kernel: the wave that sees only sky)
+        const float t = 0.5f * (rd0.y + 1.0f);
+        const float omt = 1.0f - t;
+        const float sr = omt + 0.5f * t, sg = omt + 0.7f * t, sb = omt + 1.0f * t;
+        int sample = p.first_sample;
+        for (int k = 0; k < p.num_samples; ++k) {
+            if (p.accum_mode == 0) {
+                if (mr == sr && mg == sg && mb == sb) break;
+                const float a = ieee_rcp((float)sample);
+                mr = mr + a * (sr - mr);
+                mg = mg + a * (sg - mg);
+                mb = mb + a * (sb - mb);
+            } else {
+                mr += sr; mg += sg; mb += sb;
+            }
+            sample += p.sample_stride;
+        }
+        const float alpha = p.accum_mode == 0 ? 1.0f : prev.w + (float)p.num_samples;
+        reinterpret_cast<float4*>(p.dst)[pix] = make_float4(mr, mg, mb, alpha);
+        // what a render kernel leaves for a pixel whose camera ray misses
+        if (p.primary_cache && !p.primary_cache_valid) p.primary_cache[pix] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xffffffffu));
+    }
+    // queries in the reference's sense: the camera ray's, once per sample (none of them evaluated here)
+    const unsigned long long lanes = (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(mine));
+    if (threadIdx.x == 0 && lanes) atomicAdd(&p.counters[(size_t)(blockIdx.x % PT_COUNTER_SLOTS) * PT_COUNTER_STRIDE], lanes * (unsigned long long)p.num_samples);
+}
+
+int window_tiles(const PtKernelParams& p) { return p.pixel_list ? p.pixel_tiles : PT_TILES_ACROSS(p.win_w) * PT_TILES_ACROSS(p.win_h); }
 }  // namespace
 
 hipError_t pt_launch_prepare_triangles(const float* vertices, const uint32_t* indices, int32_t num_triangles,
@@ -2520,6 +2617,27 @@ __global__ __launch_bounds__(PT_COUNTER_SLOTS) void pt_grid_occ_flag_kernel(cons
 
 hipError_t pt_launch_grid_occ_flag(const unsigned long long* counters, unsigned long long samples, uint32_t* flag, hipStream_t stream) {
     hipLaunchKernelGGL(pt_grid_occ_flag_kernel, dim3(1), dim3(PT_COUNTER_SLOTS), 0, stream, counters, samples, flag);
+    return hipGetLastError();
+}
+
+hipError_t pt_launch_pixel_list(const PtKernelParams& p, unsigned long long* mask, uint32_t* counts, uint32_t* offsets, uint32_t* list, uint32_t* total,
+                                hipStream_t stream) {
+    if (p.pixel_list != nullptr || p.grid_cells == nullptr || PT_TILE_WAVES != 1 || p.win_w <= 0 || p.win_h <= 0 || p.width > 65535 || p.height > 65535)
+        return hipErrorInvalidValue;
+    const int blocks = window_tiles(p);
+    const size_t words = ((size_t)p.win_w * p.win_h + 63) / 64 * 64;
+    hipError_t e = hipMemsetAsync(list, 0xff, words * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(pt_pixel_mask_kernel, dim3(blocks), dim3(64), 0, stream, p, mask, counts);
+    hipLaunchKernelGGL(pt_pixel_offsets_kernel, dim3(1), dim3(1024), 0, stream, counts, blocks, offsets, total);
+    hipLaunchKernelGGL(pt_pixel_scatter_kernel, dim3(blocks), dim3(64), 0, stream, p, mask, offsets, list);
+    return hipGetLastError();
+}
+
+hipError_t pt_launch_sky_fold(const PtKernelParams& p, const unsigned long long* mask, hipStream_t stream) {
+    if (p.pixel_list != nullptr || PT_TILE_WAVES != 1) return hipErrorInvalidValue;
+    if (p.win_w <= 0 || p.win_h <= 0 || p.num_samples <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pt_sky_fold_kernel, dim3(window_tiles(p)), dim3(64), 0, stream, p, mask);
     return hipGetLastError();
 }
 

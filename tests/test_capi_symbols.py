@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in pt_hip.h but not exported"
     assert sorted(capi.SIGNATURES) == names, "python binding table and header disagree"
-    assert lib.pt_abi_version() == 6
+    assert lib.pt_abi_version() == 7
 
 
 def test_no_device_is_a_status_not_a_crash():
