@@ -257,7 +257,7 @@ hipError_t pt_launch_primary(const PtKernelParams& p, int program_kind, hipStrea
 // Sparse views (see PtKernelParams::pixel_list). `p` describes the view and its direction grid (pixel_list null).
 // pt_launch_pixel_list: mask[b] <- which pixels of the window's 8x8 block b have a camera ray that hits the mesh (bit l = lane l),
 // list <- those pixels block after block, padded with PT_NO_PIXEL to a multiple of 64 (`list` holds one word per window pixel,
-// rounded up to 64), *total <- how many. counts / offsets: one word per block each (scratch).
+// rounded up to 64), total[0] <- how many, total[1] <- how many blocks hold at least one. counts / offsets: one word per block each (scratch).
 // pt_launch_sky_fold: what the render kernels do for the window's OTHER pixels (every sample is the sky colour of the camera
 // ray): folds p.num_samples samples from p.src into p.dst, counts their rays, fills their primary-cache entries when asked.
 #define PT_NO_PIXEL 0xffffffffu

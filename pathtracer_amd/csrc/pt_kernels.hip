@@ -2463,14 +2463,22 @@ __global__ __launch_bounds__(64) void pt_pixel_mask_kernel(const PtKernelParams 
     }
 }
 
-// offsets <- exclusive prefix sums of counts[0..n), *total <- their sum (one workgroup: a few hundred thousand blocks at most)
+// offsets <- exclusive prefix sums of counts[0..n), total[0] <- their sum, total[1] <- how many of them are not zero (one
+// workgroup: a few hundred thousand blocks at most)
 __global__ __launch_bounds__(1024) void pt_pixel_offsets_kernel(const uint32_t* __restrict__ counts, int n, uint32_t* __restrict__ offsets, uint32_t* __restrict__ total) {
     __shared__ uint32_t part[1024];
+    __shared__ uint32_t nonzero;
+    if (threadIdx.x == 0) nonzero = 0u;
+    __syncthreads();
     const int per = (n + 1023) / 1024;
     const int begin = (int)threadIdx.x * per, end = begin + per < n ? begin + per : n;
-    uint32_t sum = 0;
-    for (int i = begin; i < end; ++i) sum += counts[i];
+    uint32_t sum = 0, some = 0;
+    for (int i = begin; i < end; ++i) {
+        sum += counts[i];
+        some += counts[i] != 0u;
+    }
     part[threadIdx.x] = sum;
+    if (some) atomicAdd(&nonzero, some);
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
         const uint32_t v = threadIdx.x >= (unsigned)off ? part[threadIdx.x - off] : 0u;
@@ -2483,7 +2491,10 @@ __global__ __launch_bounds__(1024) void pt_pixel_offsets_kernel(const uint32_t* 
         offsets[i] = run;
         run += counts[i];
     }
-    if (threadIdx.x == 1023) *total = part[1023];
+    if (threadIdx.x == 1023) {
+        total[0] = part[1023];
+        total[1] = nonzero;
+    }
 }
 
 __global__ __launch_bounds__(64) void pt_pixel_scatter_kernel(const PtKernelParams p, const unsigned long long* __restrict__ mask,

@@ -77,7 +77,7 @@ def test_gathered_hit_pixels_render_the_same(workload, size, spp, shading, accum
     assert not any(out["0"][3])
     # forced: every dispatch of a view that has a direction grid (the materials mode builds it with a view's second dispatch)
     assert out["1"][3] == ([True] * 5 if shading == "reference" else [False] + [True] * 4)
-    # the library's own rule: from a view's second dispatch on, dispatches of 8 samples or more, views where at most 3/4 of the pixels see the mesh
+    # the library's own rule: from a view's second dispatch on, dispatches of 8 samples or more, views whose occupied 8x8 blocks would leave 1/32 or more of their lanes to sky pixels
     if workload in ("suzanne", "monkeyhead2", "instanced"):
         assert out[None][3] == [False, True, True, True, False]
 

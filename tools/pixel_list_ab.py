@@ -48,9 +48,11 @@ def main():
                 st = t.stats()
                 times[mode].append(st["last_dispatch_ms"])
                 util[mode] = st["rays_traced"] / max(1, st["lane_slots"])
+                if mode == "1":
+                    hits = st["gathered_pixels"]
         print(json.dumps({"workload": workload, "spp": spp, "shading": args.shading, "blocks_ms": round(statistics.median(times["0"]), 3),
                           "gathered_ms": round(statistics.median(times["1"]), 3), "lane_utilisation": [round(util["0"], 4), round(util["1"], 4)],
-                          "same_image": same}))
+                          "pixels_that_see_the_mesh": round(hits / (scene.width * scene.height), 4), "same_image": same}))
         for t in tracers.values():
             t.close()
 
