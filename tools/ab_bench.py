@@ -30,7 +30,8 @@ VARIANTS = {
     "leaf1": ["-DPT_BVH_WIDE_LEAF_MAX=1"], "leaf4": ["-DPT_BVH_WIDE_LEAF_MAX=4"], "steps1": ["-DPT_WALK_NODE_STEPS=1"], "steps2": ["-DPT_WALK_NODE_STEPS=2"], "steps2b24": ["-DPT_WALK_NODE_STEPS=2", "-DPT_SHADE_BATCH=24"],
     "steps2b32": ["-DPT_WALK_NODE_STEPS=2", "-DPT_SHADE_BATCH=32"], "steps4": ["-DPT_WALK_NODE_STEPS=4"],
     "waves4": ["-DPT_DECOUPLED_MIN_WAVES=4"], "waves6": ["-DPT_DECOUPLED_MIN_WAVES=6"],
-    "batch12": ["-DPT_SHADE_BATCH=12"], "batch24": ["-DPT_SHADE_BATCH=24"],
+    "batch12": ["-DPT_SHADE_BATCH=12"], "batch24": ["-DPT_SHADE_BATCH=24"], "b16": ["-DPT_SHADE_BATCH=16"], "b32": ["-DPT_SHADE_BATCH=32"], "b40": ["-DPT_SHADE_BATCH=40"],
+    "s1": ["-DPT_WALK_NODE_STEPS=1"], "s3": ["-DPT_WALK_NODE_STEPS=3"],
     "reshade": ["-DPT_V_RESHADE"],   # materials loop: a lane whose sample ended in Shade() shades its next sample's camera hit in the same trip
     "sub4": ["-DPT_SCHED_SUB_LOG=2"], "sub16": ["-DPT_SCHED_SUB_LOG=4"],   # work list: 4 / 16 cost buckets to an octave (16 / 4 octaves) instead of 8
     "live": ["-DPT_V_LIVE_COUNT"],   # direction grid: lanes still in the loop summed over the wave trips -> bvh_node_fetches (lane_slots minus that = slots of lanes whose pixel is finished)
