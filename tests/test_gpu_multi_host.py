@@ -26,6 +26,18 @@ def test_tile_partition_over_logical_ranks_is_bit_exact(workload, size, ranks, b
     from pathtracer_amd import host_api
     W, H = size
     passes, batch = 12, 5                                  # frames of 5, 5 and 2 samples
+    _tile_partition_case(host_api, workload, W, H, passes, batch, shading, ranks, block_rows)
+
+
+def test_tile_partition_with_gathered_pixels():
+    """Frames of ten samples: from a view's second frame on every rank renders the hit pixels of ITS rows gathered into tiles of 64
+    (the list is per row partition), the single context those of the whole frame."""
+    from pathtracer_amd import host_api
+    _tile_partition_case(host_api, "monkeyhead2", 320, 180, 44, 10, "reference", 3, 16)
+    _tile_partition_case(host_api, "suzanne", 256, 144, 36, 12, "materials", 2, 8)
+
+
+def _tile_partition_case(host_api, workload, W, H, passes, batch, shading, ranks, block_rows):
     want, want8, st = _single(workload, W, H, passes, batch, shading)
     for every_frame in (True, False):
         got, got8, mst = host_api.render_workload(workload, W, H, passes, batch, shading, devices=[0] * ranks, partition="tile",
@@ -35,12 +47,13 @@ def test_tile_partition_over_logical_ranks_is_bit_exact(workload, size, ranks, b
         assert mst["samples"] == st["samples"] == W * H * passes and mst["rays"] == st["rays"] and not mst["rccl"]
 
 
-@pytest.mark.parametrize("workload,size,ranks,shading", [("monkeyhead2", (320, 180), 4, "reference"), ("world", (256, 144), 3, "reference"),
-                                                          ("instanced", (480, 270), 2, "materials")])
-def test_sample_partition_over_logical_ranks(workload, size, ranks, shading):
+@pytest.mark.parametrize("workload,size,ranks,shading,passes,batch", [("monkeyhead2", (320, 180), 4, "reference", 50, 6), ("world", (256, 144), 3, "reference", 50, 6),
+                                                                       ("instanced", (480, 270), 2, "materials", 50, 6),
+                                                                       ("instanced", (480, 270), 3, "reference", 130, 36)])   # frames long enough for gathered pixels
+def test_sample_partition_over_logical_ranks(workload, size, ranks, shading, passes, batch):
     from pathtracer_amd import host_api
     W, H = size
-    passes, batch = 50, 6                                  # 50 samples over the ranks: residue classes of unequal length
+    # (50 samples over the ranks: residue classes of unequal length)
     want, _, st = _single(workload, W, H, passes, batch, shading)
     got, _, mst = host_api.render_workload(workload, W, H, passes, batch, shading, devices=[0] * ranks, partition="sample", exchange="host")
     scale = 1.0 / passes
