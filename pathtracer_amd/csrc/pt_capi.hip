@@ -230,7 +230,8 @@ struct PtContext {
         float camera[12];
         int32_t win[4], rows[3], size[2], num_triangles;
         uint32_t grid_id;
-    } pixel_list_key{};
+    } pixel_list_key{}, last_view_key{};   // (last_view_key: what the previous pt_dispatch rendered, grid_id left 0)
+    bool last_view_valid = false;
     uint32_t grid_id = 0;           // counts the builds of the direction grid
     bool use_pixel_list = false;    // what pt_dispatch decided for its launches
     bool last_gathered = false;     // ... and what the last dispatch did (PtStats::gathered_pixels)
@@ -333,6 +334,7 @@ void free_target(PtContext* ctx) {
     ctx->d_pixel_list = ctx->d_pixel_counts = ctx->d_pixel_offsets = ctx->d_pixel_total = nullptr;
     ctx->d_pixel_mask = nullptr;
     ctx->pixel_list_valid = false;
+    ctx->last_view_valid = false;
     ctx->use_pixel_list = false;
     ctx->sched_numbering = 0;
     if (ctx->d_sample_scratch) (void)hipFree(ctx->d_sample_scratch);
@@ -1261,10 +1263,6 @@ namespace {
 constexpr int kPixelListMinSamples = 8;   // shorter dispatches (frame loops) keep the window's blocks: the sky pass would cost them more than the idle lanes
 PtStatus choose_pixel_list(PtContext* ctx, const PtKernelParams& p, const Program* prog, int32_t num_samples) {
     ctx->use_pixel_list = false;
-    if (PT_TILE_WAVES != 1 || ctx->pixel_list_mode == 0 || prog->kind != PT_PROGRAM_MESH || p.grid_cells == nullptr || !ctx->primary_reuse || p.depth <= 0 ||
-        ctx->sched_mode == 0 || ctx->d_pixel_list == nullptr || ctx->no_alloc)
-        return PT_OK;
-    if (ctx->pixel_list_mode != 1 && num_samples < kPixelListMinSamples) return PT_OK;
     PtContext::PixelListKey key;
     memset(&key, 0, sizeof key);
     memcpy(key.camera, p.ro, 12); memcpy(key.camera + 3, p.llc, 12); memcpy(key.camera + 6, p.hor, 12); memcpy(key.camera + 9, p.ver, 12);
@@ -1272,9 +1270,18 @@ PtStatus choose_pixel_list(PtContext* ctx, const PtKernelParams& p, const Progra
     key.rows[0] = p.row_block; key.rows[1] = p.row_index; key.rows[2] = p.row_count;
     key.size[0] = ctx->width; key.size[1] = ctx->height;
     key.num_triangles = p.num_triangles;
+    // A view that stays: the previous pt_dispatch rendered the same camera (position AND orientation), window and partition. A
+    // camera that turns from frame to frame never gets a list: every new list renumbers the tiles, which drops their costs.
+    const bool view_stays = ctx->last_view_valid && memcmp(&key, &ctx->last_view_key, sizeof key) == 0;
+    ctx->last_view_key = key;
+    ctx->last_view_valid = true;
+    if (PT_TILE_WAVES != 1 || ctx->pixel_list_mode == 0 || prog->kind != PT_PROGRAM_MESH || p.grid_cells == nullptr || !ctx->primary_reuse || p.depth <= 0 ||
+        ctx->sched_mode == 0 || ctx->d_pixel_list == nullptr || ctx->no_alloc)
+        return PT_OK;
+    if (ctx->pixel_list_mode != 1 && num_samples < kPixelListMinSamples) return PT_OK;
     key.grid_id = ctx->grid_id;
     if (!ctx->pixel_list_valid || memcmp(&key, &ctx->pixel_list_key, sizeof key) != 0) {
-        if (ctx->pixel_list_mode != 1 && ctx->dispatches_here < 1) return PT_OK;   // a view that stays: from its second dispatch on
+        if (ctx->pixel_list_mode != 1 && !view_stays) return PT_OK;
         ctx->pixel_list_valid = false;
         PT_HIP_TRY(pt_launch_pixel_list(p, ctx->d_pixel_mask, ctx->d_pixel_counts, ctx->d_pixel_offsets, ctx->d_pixel_list, ctx->d_pixel_total, ctx->stream));
         uint32_t counted[2] = {0, 0};

@@ -81,3 +81,25 @@ def test_gathered_hit_pixels_render_the_same(workload, size, spp, shading, accum
     if workload in ("suzanne", "monkeyhead2", "instanced"):
         assert out[None][3] == [False, True, True, True, False]
 
+
+
+def test_a_camera_that_turns_every_frame_gets_no_list():
+    """Every list renumbers the tiles and so drops the scheduler's costs: the library builds one only when the previous dispatch
+    rendered the same camera (orientation included), window and partition."""
+    from pathtracer_amd.scenes import SceneData
+    scene = SceneData("monkeyhead2", 480, 270)
+    with _tracer(None) as t:
+        scene.upload(t)
+        t.target_create(scene.width, scene.height)
+        cam = np.array(scene.camera, np.float32).copy()
+        used = []
+        for k in range(5):
+            cam[3:6] += np.float32(0.002)       # the lower left corner of the image plane moves: the camera turns, its position stays
+            t.set_uniforms(cam, scene.num_triangles, 10)
+            t.dispatch(1, 16, 1)
+            used.append(t.stats()["gathered_pixels"] > 0)
+        for k in range(3):                      # ... and then stays
+            t.dispatch(17 + 16 * k, 16, 1)
+            used.append(t.stats()["gathered_pixels"] > 0)
+        t.finish()
+    assert used == [False] * 5 + [True] * 3
